@@ -1,0 +1,148 @@
+/*
+ * qkgram.h -- C ABI of the MI355X (gfx950) quantum-kernel Gram engine.
+ *
+ * Drop-in boundary for ONE hot path of mmetcalf14/qml-cutensornet: filling
+ *     K[j, i] = |<psi(x_i)|psi(y_j)>|^2
+ * from matrix-product states.  Each entry point below names the reference
+ * interface it replaces.  Short names:
+ *     G = gpu_backend/kernel_state_ansatz.py     (reference, GPU backend)
+ *     J = KernelPkg/src/KernelPkg.jl             (reference, CPU engine)
+ *
+ * Conventions
+ *   - every function returns 0 on success, a negative QK_E* code otherwise;
+ *     qk_last_error() gives a thread-local message.  No exception, callback or
+ *     C++/torch type crosses this ABI: plain pointers and sizes only.
+ *   - the library is batch-first: nothing here is called per Gram entry.
+ *   - the caller owns host buffers; the library owns device memory behind
+ *     opaque handles.  Calls on one context are serialised by the caller.
+ *   - "device pointer" arguments are plain HIP device addresses (for example
+ *     torch.Tensor.data_ptr()); work is enqueued on the context's stream.
+ *   - there is NO CPU fallback: without a usable gfx950 device
+ *     qk_ctx_create() fails and nothing else can be called.
+ */
+#ifndef QKGRAM_H
+#define QKGRAM_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define QK_OK 0
+#define QK_EINVAL (-1)   /* bad argument / inconsistent shapes            */
+#define QK_EDEVICE (-2)  /* HIP error (no device, launch/alloc failure)   */
+#define QK_ENOMEM (-3)   /* host allocation failure                       */
+
+/* host layout of one site tensor handed to qk_mps_set_create() */
+#define QK_LAYOUT_LPR 0 /* [left bond][physical][right bond], C order */
+#define QK_LAYOUT_LRP 1 /* [left bond][right bond][physical], C order */
+
+/* flags of qk_plan_create() */
+#define QK_PLAN_SYMMETRIC 1u /* Y is X: compute i <= j only, mirror on scatter (G:390-395) */
+
+typedef struct qk_ctx qk_ctx;         /* one per device; replaces CuTensorNetHandle(device_id), G:213,255,366 */
+typedef struct qk_mps_set qk_mps_set; /* a device-resident list of MPS; replaces the per-rank lists of
+                                         pytket-cutensornet MPS objects mps_x_chunk / mps_y_chunk, G:210,252,290 */
+typedef struct qk_plan qk_plan;       /* ordered list of (x, y) pairs assigned to one rank; replaces the chunk /
+                                         round-robin bookkeeping of G:154,184,331-334,384-385 */
+
+/* Algorithmic work of the last gram launch: complex128,
+ * 8 real flops per complex multiply-add, each site tensor of both operands
+ * read once per pair.  kernel_ms is the HIP-event time of the sweep kernel
+ * on the context's stream (0 until the events have completed). */
+typedef struct qk_stats {
+  int64_t pairs;
+  double flops;        /* sum over pairs and sites of 8*(a*b*2*b' + 2*a*a'*b')        */
+  double padded_flops; /* the same with every bond rounded up to the MFMA tile (16)   */
+  double bytes;        /* sum over pairs of 16*2*sum_k(a_k a_k+1 + b_k b_k+1) + 8     */
+  double kernel_ms;    /* device time of the last sweep launch                        */
+  int32_t grid;        /* workgroups launched                                         */
+  int32_t max_bond;    /* largest padded bond among the two sets                      */
+} qk_stats;
+
+const char* qk_last_error(void);
+
+/* number of gfx950 devices visible to the process (0 if none); replaces
+ * cupy.cuda.runtime.getDeviceCount(), G:5,152 */
+int qk_device_count(void);
+
+/* ---- context --------------------------------------------------------------- */
+int qk_ctx_create(int device_id, qk_ctx** out);
+int qk_ctx_destroy(qk_ctx* ctx);
+/* run subsequent work on this hipStream_t (NULL = the context's own stream) */
+int qk_ctx_set_stream(qk_ctx* ctx, void* hip_stream);
+int qk_ctx_synchronize(qk_ctx* ctx);
+
+/* ---- MPS sets ---------------------------------------------------------------
+ * Upload n_states MPS of n_sites sites each.
+ *   bond_dims    [n_states][n_sites+1] int32, bond_dims[s][0] = bond_dims[s][n_sites] = 1
+ *   site_tensors [n_states][n_sites]   host pointers to complex128 (re,im interleaved)
+ *                arrays of shape (chi_k, 2, chi_k+1) in `layout`
+ * Replaces keeping pytket-cutensornet MPS objects (cupy tensors) alive on the
+ * device between simulate() and vdot(), G:221-226, 290, 370-374.
+ * Device layout: per site, split re/im planes [chi_k^][2][chi_k+1^] with every
+ * bond zero-padded to a multiple of 16 (the f64 MFMA tile).                    */
+int qk_mps_set_create(qk_ctx* ctx, int32_t n_states, int32_t n_sites, const int32_t* bond_dims,
+                      const double* const* site_tensors, int32_t layout, qk_mps_set** out);
+int qk_mps_set_destroy(qk_mps_set* set);
+int qk_mps_set_info(const qk_mps_set* set, int32_t* n_states, int32_t* n_sites, int32_t* max_padded_bond,
+                    int64_t* device_bytes);
+
+/* Host-only packing helper used by qk_mps_set_create (exported so that the
+ * packing can be unit-tested without a GPU).  Writes one state's padded planar
+ * image; `out` must hold qk_pack_state_size() doubles.                         */
+int64_t qk_pack_state_size(int32_t n_sites, const int32_t* bond_dims);
+int qk_pack_state(int32_t n_sites, const int32_t* bond_dims, const double* const* site_tensors, int32_t layout,
+                  double* out, int64_t* site_offsets /* [n_sites] offsets of each re-plane, in doubles */);
+
+/* ---- plans (host side; no GPU needed) ---------------------------------------
+ * Enumerate the pairs of the Gram, order them for cache locality (tiles of
+ * `block` x `block` states) and, inside a tile, by decreasing estimated cost,
+ * then deal them round-robin to `world_size` ranks and keep rank `rank`'s
+ * share.  x_dims / y_dims are the bond_dims tables of the two sets
+ * (y_dims = NULL with QK_PLAN_SYMMETRIC).  Pairs are (x index i, y index j);
+ * the Gram entry is K[j][i]  (rows = Y, cols = X: G:387, J:106).               */
+int qk_plan_create(int32_t n_sites, int32_t nx, const int32_t* x_dims, int32_t ny, const int32_t* y_dims,
+                   uint32_t flags, int32_t world_size, int32_t rank, int32_t block, qk_plan** out);
+int qk_plan_destroy(qk_plan* plan);
+int64_t qk_plan_num_pairs(const qk_plan* plan);       /* this rank's pairs              */
+int64_t qk_plan_total_pairs(const qk_plan* plan);     /* all ranks                      */
+int64_t qk_plan_max_pairs_per_rank(const qk_plan* plan);
+const int32_t* qk_plan_pairs(const qk_plan* plan);    /* [num_pairs][2] = (i, j), host  */
+int qk_plan_stats(const qk_plan* plan, qk_stats* out); /* algorithmic flops/bytes of this rank's share */
+
+/* ---- the hot path -----------------------------------------------------------
+ * qk_gram_values: for every pair p of the plan compute z_p = <x_i|y_j> and write
+ *     values_dev[p] = |z_p|^2                 (G:380-383, J:106)
+ *     z_dev[2p], z_dev[2p+1] = re, im of z_p  (optional, may be NULL)
+ * One persistent launch; returns after enqueueing (asynchronous).
+ * yset = NULL means Y is X.                                                    */
+int qk_gram_values(qk_ctx* ctx, const qk_mps_set* xset, const qk_mps_set* yset, const qk_plan* plan,
+                   double* values_dev, double* z_dev);
+
+/* Scatter packed values into the dense matrix K (device, row-major, leading
+ * dimension ld): K[j][i] = v, and K[i][j] = v as well when `mirror` != 0
+ * (G:387, 390-395).  pairs_dev: [n][2] int32 on the device.                    */
+int qk_scatter(qk_ctx* ctx, const int32_t* pairs_dev, const double* values_dev, int64_t n, double* k_dev,
+               int64_t ld, int32_t mirror);
+
+/* Convenience, synchronous: whole Gram of xset (cols) vs yset (rows, NULL =
+ * symmetric) into a host matrix out[ny][ld].  Replaces the double loop
+ * G:372-400 plus the final reduce G:428 for a single process.                  */
+int qk_gram_host(qk_ctx* ctx, const qk_mps_set* xset, const qk_mps_set* yset, double* out, int64_t ld);
+
+/* Convenience, synchronous: complex overlaps z[j][i] = <x_i|y_j> (re,im
+ * interleaved, out[ny][nx][2]); the batched form of MPS.vdot, G:380.           */
+int qk_overlaps_host(qk_ctx* ctx, const qk_mps_set* xset, const qk_mps_set* yset, double* out);
+
+int qk_get_stats(qk_ctx* ctx, qk_stats* out);
+
+/* Device self-test of the f64 MFMA fragment maps the kernels rely on (returns
+ * 0 if the 16x16x4 product of two known matrices matches the host result). */
+int qk_selftest_mfma(qk_ctx* ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* QKGRAM_H */

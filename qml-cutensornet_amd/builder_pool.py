@@ -1,0 +1,58 @@
+"""Build many MPS on the host cores in parallel (input production, outside the hot path).
+
+Stands in for the per-rank ``simulate`` loop of the reference
+(/root/reference/gpu_backend/kernel_state_ansatz.py:213-231): every data point
+is independent, so the points are dealt to a process pool with BLAS pinned to one
+thread per worker.
+"""
+from __future__ import annotations
+
+import multiprocessing as mp
+import os
+import time
+
+import numpy as np
+
+from .mps import MPS, simulate
+
+_G = {}
+
+
+def _init(ansatz, fidelity):
+    for v in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS"):
+        os.environ[v] = "1"
+    try:
+        from threadpoolctl import threadpool_limits
+
+        _G["tp"] = threadpool_limits(1)
+    except Exception:  # pragma: no cover - threadpoolctl is optional
+        pass
+    _G["ansatz"], _G["fid"] = ansatz, fidelity
+
+
+def _one(x):
+    t0 = time.perf_counter()
+    m = simulate(_G["ansatz"].circuit_for_data(x), _G["fid"])
+    return m.tensors, m.fidelity, time.perf_counter() - t0
+
+
+def default_workers() -> int:
+    try:
+        return max(1, len(os.sched_getaffinity(0)))
+    except AttributeError:  # pragma: no cover
+        return max(1, os.cpu_count() or 1)
+
+
+def build_states(ansatz, X, truncation_fidelity, workers=None):
+    """Return (list[MPS], per-state build seconds) for the rows of ``X``."""
+    X = np.asarray(X, dtype=np.float64)
+    workers = default_workers() if workers is None else int(workers)
+    workers = min(workers, len(X)) or 1
+    if workers <= 1:
+        _init(ansatz, truncation_fidelity)
+        res = [_one(x) for x in X]
+    else:
+        ctx = mp.get_context("fork")
+        with ctx.Pool(workers, initializer=_init, initargs=(ansatz, truncation_fidelity)) as pool:
+            res = pool.map(_one, list(X), chunksize=1)
+    return [MPS(t, f) for t, f, _ in res], [dt for _, _, dt in res]

@@ -1,0 +1,781 @@
+// qkgram.hip -- MI355X (gfx950 / CDNA4) engine for the quantum-kernel Gram hot path.
+//
+// What it replaces (reference = mmetcalf14/qml-cutensornet, G = gpu_backend/kernel_state_ansatz.py):
+//   G:372-400  the Python double loop calling  x_mps.vdot(y_mps)  once per Gram entry
+//   G:380      MPS.vdot -> one cuTensorNet contraction + a device->host sync per entry
+// by ONE persistent kernel launch per Gram share: every workgroup pulls (x_i, y_j) pairs
+// from a device-side queue and carries the whole transfer-matrix sweep
+//     X_0 = 1,   X_{k+1}[r,R] = sum_{L,l,p} X_k[l,L] * conj(A_k[L,p,R]) * B_k[l,p,r]
+// on chip/L2 as a chain of complex GEMMs on the f64 matrix cores
+// (v_mfma_f64_16x16x4_f64), and finally writes |<x|y>|^2.
+//
+// Written for gfx950 only: 64-lane wavefronts, 160 KiB LDS per CU, no portability layer.
+#include "../../include/qkgram.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <numeric>
+#include <string>
+#include <vector>
+
+// ----------------------------------------------------------------------------------------
+// errors
+// ----------------------------------------------------------------------------------------
+static thread_local std::string g_err;
+
+static int fail(int code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  g_err = buf;
+  return code;
+}
+
+#define HIP_TRY(expr)                                                                               \
+  do {                                                                                              \
+    hipError_t e_ = (expr);                                                                         \
+    if (e_ != hipSuccess) return fail(QK_EDEVICE, "%s failed: %s", #expr, hipGetErrorString(e_));   \
+  } while (0)
+
+extern "C" const char* qk_last_error(void) { return g_err.c_str(); }
+
+// ----------------------------------------------------------------------------------------
+// shapes
+// ----------------------------------------------------------------------------------------
+static constexpr int TILE = 16;  // M/N granule of v_mfma_f64_16x16x4_f64
+static inline int pad16(int x) { return (x + TILE - 1) / TILE * TILE; }
+
+struct qk_ctx {
+  int device = 0;
+  int num_cus = 0;
+  hipStream_t own_stream = nullptr;
+  hipStream_t stream = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  bool ev_pending = false;
+  double* scratch = nullptr;
+  size_t scratch_bytes = 0;
+  unsigned long long* counter = nullptr;
+  qk_stats last{};
+};
+
+struct qk_mps_set {
+  qk_ctx* ctx = nullptr;
+  int n_states = 0, n_sites = 0, max_pad = 0;
+  double* d_data = nullptr;
+  int32_t* d_dims = nullptr;  // padded bonds [n_states][n_sites+1]
+  int64_t* d_offs = nullptr;  // re-plane offsets (doubles) [n_states][n_sites]
+  std::vector<int32_t> dims_true;
+  int64_t bytes = 0;
+};
+
+struct qk_plan {
+  int n_sites = 0, nx = 0, ny = 0;
+  bool symmetric = false;
+  int world = 1, rank = 0;
+  int64_t total_pairs = 0, max_per_rank = 0;
+  std::vector<int32_t> pairs;  // this rank, (i, j) interleaved
+  qk_stats stats{};
+  // lazily uploaded copy
+  qk_ctx* up_ctx = nullptr;
+  int32_t* d_pairs = nullptr;
+};
+
+// ----------------------------------------------------------------------------------------
+// host: packing one MPS into the padded planar device image
+// ----------------------------------------------------------------------------------------
+extern "C" int64_t qk_pack_state_size(int32_t n_sites, const int32_t* bond_dims) {
+  int64_t tot = 0;
+  for (int k = 0; k < n_sites; ++k) tot += 2ll * pad16(bond_dims[k]) * 2 * pad16(bond_dims[k + 1]);
+  return tot;
+}
+
+extern "C" int qk_pack_state(int32_t n_sites, const int32_t* bond_dims, const double* const* site_tensors,
+                             int32_t layout, double* out, int64_t* site_offsets) {
+  if (n_sites <= 0 || !bond_dims || !site_tensors || !out) return fail(QK_EINVAL, "qk_pack_state: null argument");
+  if (layout != QK_LAYOUT_LPR && layout != QK_LAYOUT_LRP) return fail(QK_EINVAL, "qk_pack_state: unknown layout %d", layout);
+  if (bond_dims[0] != 1 || bond_dims[n_sites] != 1) return fail(QK_EINVAL, "qk_pack_state: boundary bonds must be 1");
+  int64_t off = 0;
+  for (int k = 0; k < n_sites; ++k) {
+    const int cl = bond_dims[k], cr = bond_dims[k + 1];
+    if (cl <= 0 || cr <= 0) return fail(QK_EINVAL, "qk_pack_state: non-positive bond at site %d", k);
+    const int pl = pad16(cl), pr = pad16(cr);
+    const int64_t plane = (int64_t)pl * 2 * pr;
+    double* re = out + off;
+    double* im = re + plane;
+    std::memset(re, 0, sizeof(double) * 2 * plane);
+    const double* src = site_tensors[k];
+    if (!src) return fail(QK_EINVAL, "qk_pack_state: null tensor at site %d", k);
+    for (int l = 0; l < cl; ++l)
+      for (int p = 0; p < 2; ++p)
+        for (int r = 0; r < cr; ++r) {
+          const int64_t s = (layout == QK_LAYOUT_LPR) ? (((int64_t)l * 2 + p) * cr + r) : (((int64_t)l * cr + r) * 2 + p);
+          const int64_t d = ((int64_t)l * 2 + p) * pr + r;
+          re[d] = src[2 * s];
+          im[d] = src[2 * s + 1];
+        }
+    if (site_offsets) site_offsets[k] = off;
+    off += 2 * plane;
+  }
+  return QK_OK;
+}
+
+// ----------------------------------------------------------------------------------------
+// host: work model and planner
+// ----------------------------------------------------------------------------------------
+// Algorithmic flops of one overlap: 8 real flops per complex
+// multiply-add, cheaper association per site.  Padded: what this engine executes.
+static void pair_work(int n, const int32_t* a, const int32_t* b, double* flops, double* padded, double* bytes) {
+  double f = 0, fp = 0, by = 0;
+  for (int k = 0; k < n; ++k) {
+    const double a0 = a[k], a1 = a[k + 1], b0 = b[k], b1 = b[k + 1];
+    const double f1 = a0 * b0 * 2 * b1 + 2 * a0 * a1 * b1;
+    const double f2 = a0 * b0 * 2 * a1 + 2 * b0 * a1 * b1;
+    f += 8 * std::min(f1, f2);
+    const double A0 = pad16(a[k]), A1 = pad16(a[k + 1]), B0 = pad16(b[k]), B1 = pad16(b[k + 1]);
+    fp += 8 * (A0 * B0 * 2 * B1 + 2 * A0 * A1 * B1);
+    by += 16.0 * 2 * (a0 * a1 + b0 * b1);
+  }
+  *flops = f;
+  *padded = fp;
+  *bytes = by + 8;
+}
+
+extern "C" int qk_plan_create(int32_t n_sites, int32_t nx, const int32_t* x_dims, int32_t ny, const int32_t* y_dims,
+                              uint32_t flags, int32_t world_size, int32_t rank, int32_t block, qk_plan** out) {
+  if (!out || !x_dims || n_sites <= 0 || nx <= 0) return fail(QK_EINVAL, "qk_plan_create: bad argument");
+  const bool sym = (flags & QK_PLAN_SYMMETRIC) != 0;
+  if (sym) {
+    y_dims = x_dims;
+    ny = nx;
+  } else if (!y_dims || ny <= 0)
+    return fail(QK_EINVAL, "qk_plan_create: y_dims required unless symmetric");
+  if (world_size <= 0 || rank < 0 || rank >= world_size) return fail(QK_EINVAL, "qk_plan_create: bad rank %d/%d", rank, world_size);
+  if (block <= 0) block = 16;
+  qk_plan* p = new (std::nothrow) qk_plan;
+  if (!p) return fail(QK_ENOMEM, "qk_plan_create: out of memory");
+  p->n_sites = n_sites, p->nx = nx, p->ny = ny, p->symmetric = sym, p->world = world_size, p->rank = rank;
+
+  struct Item {
+    int32_t i, j;
+    float cost;
+  };
+  std::vector<Item> tile;
+  const int stride = n_sites + 1;
+  int64_t t = 0;  // running index in the global order
+  std::vector<int64_t> per_rank(world_size, 0);
+  double flops = 0, padded = 0, bytes = 0;
+  const int nbx = (nx + block - 1) / block, nby = (ny + block - 1) / block;
+  for (int bj = 0; bj < nby; ++bj)
+    for (int bi = 0; bi < nbx; ++bi) {
+      if (sym && bi > bj) continue;
+      tile.clear();
+      for (int j = bj * block; j < std::min(ny, (bj + 1) * block); ++j)
+        for (int i = bi * block; i < std::min(nx, (bi + 1) * block); ++i) {
+          if (sym && i > j) continue;
+          double f, fp, by;
+          pair_work(n_sites, x_dims + (int64_t)i * stride, y_dims + (int64_t)j * stride, &f, &fp, &by);
+          tile.push_back({i, j, (float)fp});
+        }
+      std::stable_sort(tile.begin(), tile.end(), [](const Item& u, const Item& v) { return u.cost > v.cost; });
+      for (const Item& it : tile) {
+        const int r = (int)(t % world_size);
+        ++per_rank[r];
+        if (r == rank) {
+          p->pairs.push_back(it.i);
+          p->pairs.push_back(it.j);
+          double f, fp, by;
+          pair_work(n_sites, x_dims + (int64_t)it.i * stride, y_dims + (int64_t)it.j * stride, &f, &fp, &by);
+          flops += f, padded += fp, bytes += by;
+        }
+        ++t;
+      }
+    }
+  p->total_pairs = t;
+  p->max_per_rank = *std::max_element(per_rank.begin(), per_rank.end());
+  p->stats.pairs = (int64_t)p->pairs.size() / 2;
+  p->stats.flops = flops, p->stats.padded_flops = padded, p->stats.bytes = bytes;
+  *out = p;
+  return QK_OK;
+}
+
+extern "C" int qk_plan_destroy(qk_plan* plan) {
+  if (!plan) return QK_OK;
+  if (plan->d_pairs) (void)hipFree(plan->d_pairs);
+  delete plan;
+  return QK_OK;
+}
+extern "C" int64_t qk_plan_num_pairs(const qk_plan* p) { return p ? (int64_t)p->pairs.size() / 2 : 0; }
+extern "C" int64_t qk_plan_total_pairs(const qk_plan* p) { return p ? p->total_pairs : 0; }
+extern "C" int64_t qk_plan_max_pairs_per_rank(const qk_plan* p) { return p ? p->max_per_rank : 0; }
+extern "C" const int32_t* qk_plan_pairs(const qk_plan* p) { return p ? p->pairs.data() : nullptr; }
+extern "C" int qk_plan_stats(const qk_plan* p, qk_stats* out) {
+  if (!p || !out) return fail(QK_EINVAL, "qk_plan_stats: null argument");
+  *out = p->stats;
+  return QK_OK;
+}
+
+// ----------------------------------------------------------------------------------------
+// device code
+// ----------------------------------------------------------------------------------------
+typedef double v4d __attribute__((ext_vector_type(4)));
+
+// Staging geometry of the complex GEMM: a workgroup (4 waves) produces one 64x64 complex
+// output block per pass; operands are staged k-major through LDS in K-tiles of 16 rows,
+// 4 planes (A re/im, B re/im) of [16][64] doubles, double-buffered = 64 KiB.
+static constexpr int WG_THREADS = 256;
+static constexpr int PASS = 64;
+static constexpr int KT = 16;
+static constexpr int PLANE = KT * PASS;         // doubles per staged plane
+static constexpr int STAGE = 4 * PLANE;         // doubles per buffer
+static constexpr int LDS_DOUBLES = 2 * STAGE;   // double-buffered
+static constexpr size_t LDS_BYTES = LDS_DOUBLES * sizeof(double) + 16;  // + pair slot
+
+struct SweepArgs {
+  const double* xdata;
+  const int32_t* xdims;
+  const int64_t* xoffs;
+  const double* ydata;
+  const int32_t* ydims;
+  const int64_t* yoffs;
+  int n_sites;
+  const int32_t* pairs;
+  long long npairs;
+  double* values;
+  double* z;
+  double* scratch;
+  long long x_plane;  // doubles per X plane
+  long long t_plane;  // doubles per T plane
+  unsigned long long* counter;
+};
+
+// C[M x N] = sum_k Aop[k][m] * Bop[k][n]   (complex, split planes; CONJB conjugates Bop)
+// Aop, Bop are "k-major": row k holds the M (resp. N) entries contiguously.  M, N, K are
+// multiples of 16.  All 256 threads of the workgroup call this together.
+//
+// MFMA fragment maps (v_mfma_f64_16x16x4_f64; lane = 16*q + j):
+//   A operand: lane holds Aop_tile[i = j][k = q]  -> staged element [4*ks + q][16*tm + j]
+//   B operand: lane holds Bop_tile[k = q][n = j]  -> staged element [4*ks + q][16*tn + j]
+//   C/D:       register r of the lane is C_tile[row = q + 4 r][col = j]
+template <bool CONJB>
+__device__ __forceinline__ void zgemm_kmajor(double* __restrict__ Cre, double* __restrict__ Cim, const int ldc,
+                                             const double* __restrict__ Are, const double* __restrict__ Aim, const int lda,
+                                             const double* __restrict__ Bre, const double* __restrict__ Bim, const int ldb,
+                                             const int M, const int N, const int K, double* __restrict__ lds) {
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform
+  const int j = lane & 15, q = lane >> 4;
+  // staging role of this thread: two rows (srow, srow + 8), one 16-byte column unit
+  const int srow = tid >> 5;      // 0..7
+  const int scol = (tid & 31) * 2;  // 0..62
+  const int nk = K / KT;
+
+  for (int n0 = 0; n0 < N; n0 += PASS)
+    for (int m0 = 0; m0 < M; m0 += PASS) {
+      const int mt = min(PASS / TILE, (M - m0) / TILE);
+      const int nt = min(PASS / TILE, (N - n0) / TILE);
+      const int vt = mt * nt;
+      const bool ldA = scol < mt * TILE, ldB = scol < nt * TILE;
+
+      v4d cre[4], cim[4];
+      int tm[4], tn[4];
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        cre[s] = (v4d){0, 0, 0, 0};
+        cim[s] = (v4d){0, 0, 0, 0};
+        const int t = wave + 4 * s;
+        tm[s] = (t < vt) ? (t % mt) : -1;
+        tn[s] = (t < vt) ? (t / mt) : 0;
+      }
+
+      // staging registers: [re/im plane][row half] of the A and B operands
+      double2 a0, a1, a2, a3, b0, b1, b2, b3;
+      a0 = a1 = a2 = a3 = b0 = b1 = b2 = b3 = make_double2(0.0, 0.0);
+#define QK_FETCH(kt_)                                                        \
+  do {                                                                       \
+    const long long k0_ = (long long)(kt_)*KT + srow;                        \
+    if (ldA) {                                                               \
+      const long long o0_ = k0_ * lda + m0 + scol, o1_ = o0_ + 8ll * lda;    \
+      a0 = *reinterpret_cast<const double2*>(Are + o0_);                     \
+      a1 = *reinterpret_cast<const double2*>(Are + o1_);                     \
+      a2 = *reinterpret_cast<const double2*>(Aim + o0_);                     \
+      a3 = *reinterpret_cast<const double2*>(Aim + o1_);                     \
+    }                                                                        \
+    if (ldB) {                                                               \
+      const long long o0_ = k0_ * ldb + n0 + scol, o1_ = o0_ + 8ll * ldb;    \
+      b0 = *reinterpret_cast<const double2*>(Bre + o0_);                     \
+      b1 = *reinterpret_cast<const double2*>(Bre + o1_);                     \
+      b2 = *reinterpret_cast<const double2*>(Bim + o0_);                     \
+      b3 = *reinterpret_cast<const double2*>(Bim + o1_);                     \
+    }                                                                        \
+  } while (0)
+#define QK_STASH(buf_)                                                       \
+  do {                                                                       \
+    double* base_ = lds + (buf_)*STAGE;                                      \
+    const int o0_ = srow * PASS + scol, o1_ = o0_ + 8 * PASS;                \
+    if (ldA) {                                                               \
+      *reinterpret_cast<double2*>(base_ + 0 * PLANE + o0_) = a0;             \
+      *reinterpret_cast<double2*>(base_ + 0 * PLANE + o1_) = a1;             \
+      *reinterpret_cast<double2*>(base_ + 1 * PLANE + o0_) = a2;             \
+      *reinterpret_cast<double2*>(base_ + 1 * PLANE + o1_) = a3;             \
+    }                                                                        \
+    if (ldB) {                                                               \
+      *reinterpret_cast<double2*>(base_ + 2 * PLANE + o0_) = b0;             \
+      *reinterpret_cast<double2*>(base_ + 2 * PLANE + o1_) = b1;             \
+      *reinterpret_cast<double2*>(base_ + 3 * PLANE + o0_) = b2;             \
+      *reinterpret_cast<double2*>(base_ + 3 * PLANE + o1_) = b3;             \
+    }                                                                        \
+  } while (0)
+
+      QK_FETCH(0);
+      QK_STASH(0);
+      __syncthreads();
+      for (int kt = 0; kt < nk; ++kt) {
+        if (kt + 1 < nk) QK_FETCH(kt + 1);
+        const double* base = lds + (kt & 1) * STAGE;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          if (tm[s] >= 0) {
+            const double* pa = base + q * PASS + tm[s] * TILE + j;
+            const double* pb = base + 2 * PLANE + q * PASS + tn[s] * TILE + j;
+#pragma unroll
+            for (int ks = 0; ks < KT / 4; ++ks) {
+              const double ar = pa[ks * 4 * PASS];
+              const double ai = pa[PLANE + ks * 4 * PASS];
+              const double br = pb[ks * 4 * PASS];
+              double bi = pb[PLANE + ks * 4 * PASS];
+              if (CONJB) bi = -bi;
+              cre[s] = __builtin_amdgcn_mfma_f64_16x16x4f64(ar, br, cre[s], 0, 0, 0);
+              cre[s] = __builtin_amdgcn_mfma_f64_16x16x4f64(-ai, bi, cre[s], 0, 0, 0);
+              cim[s] = __builtin_amdgcn_mfma_f64_16x16x4f64(ar, bi, cim[s], 0, 0, 0);
+              cim[s] = __builtin_amdgcn_mfma_f64_16x16x4f64(ai, br, cim[s], 0, 0, 0);
+            }
+          }
+        }
+        if (kt + 1 < nk) QK_STASH((kt + 1) & 1);
+        __syncthreads();
+      }
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        if (tm[s] >= 0) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const long long o = (long long)(m0 + tm[s] * TILE + q + 4 * r) * ldc + n0 + tn[s] * TILE + j;
+            Cre[o] = cre[s][r];
+            Cim[o] = cim[s][r];
+          }
+        }
+      }
+    }
+#undef QK_FETCH
+#undef QK_STASH
+  // make this phase's output visible to the whole workgroup before the next phase reads it
+  __syncthreads();
+}
+
+// One persistent workgroup = one (x_i, y_j) overlap at a time, pulled from a global queue.
+//   X  [b x a]       environment, stored k-major for phase 1: X[l][L]        (scratch, L2-resident)
+//   T  [a x 2b']     T[L][(p,r)] = sum_l X[l][L] B[l][(p,r)]                 (phase 1)
+//   X' [b' x a']     X'[r][R]   = sum_{(L,p)} T[(L,p)][r] conj(A[(L,p)][R])  (phase 2; T re-read as a [2a x b'] k-major matrix)
+__global__ __launch_bounds__(WG_THREADS, 2) void qk_sweep_kernel(const SweepArgs g) {
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  long long* slot = reinterpret_cast<long long*>(lds + LDS_DOUBLES);
+
+  double* Xre = g.scratch + (long long)blockIdx.x * 2 * (g.x_plane + g.t_plane);
+  double* Xim = Xre + g.x_plane;
+  double* Tre = Xim + g.x_plane;
+  double* Tim = Tre + g.t_plane;
+  const int tid = threadIdx.x;
+
+  for (;;) {
+    if (tid == 0) *slot = (long long)atomicAdd(g.counter, 1ull);
+    __syncthreads();
+    const long long p = *slot;
+    __syncthreads();
+    if (p >= g.npairs) break;
+    const int xi = g.pairs[2 * p], yj = g.pairs[2 * p + 1];
+    const int32_t* xd = g.xdims + (long long)xi * (g.n_sites + 1);
+    const int32_t* yd = g.ydims + (long long)yj * (g.n_sites + 1);
+    const int64_t* xo = g.xoffs + (long long)xi * g.n_sites;
+    const int64_t* yo = g.yoffs + (long long)yj * g.n_sites;
+
+    // X_0 = 1 (1x1) in a zero 16x16 block
+    {
+      const int a = xd[0], b = yd[0];
+      for (int e = tid; e < a * b; e += WG_THREADS) {
+        Xre[e] = (e == 0) ? 1.0 : 0.0;
+        Xim[e] = 0.0;
+      }
+      __syncthreads();
+    }
+    for (int k = 0; k < g.n_sites; ++k) {
+      const int a = xd[k], a2 = xd[k + 1], b = yd[k], b2 = yd[k + 1];
+      const double* Are = g.xdata + xo[k];
+      const double* Aim = Are + (long long)a * 2 * a2;
+      const double* Bre = g.ydata + yo[k];
+      const double* Bim = Bre + (long long)b * 2 * b2;
+      // phase 1: T[a x 2 b2] = X^T B      (A-operand X: K = b rows of a; B-operand B: K = b rows of 2 b2)
+      zgemm_kmajor<false>(Tre, Tim, 2 * b2, Xre, Xim, a, Bre, Bim, 2 * b2, a, 2 * b2, b, lds);
+      // phase 2: X'[b2 x a2] = T^T conj(A) (A-operand T as [2a][b2]; B-operand A as [2a][a2])
+      zgemm_kmajor<true>(Xre, Xim, a2, Tre, Tim, b2, Are, Aim, a2, b2, a2, 2 * a, lds);
+    }
+    if (tid == 0) {
+      const double re = Xre[0], im = Xim[0];
+      g.values[p] = re * re + im * im;
+      if (g.z) {
+        g.z[2 * p] = re;
+        g.z[2 * p + 1] = im;
+      }
+    }
+    __syncthreads();
+  }
+}
+
+__global__ void qk_scatter_kernel(const int32_t* __restrict__ pairs, const double* __restrict__ vals, long long n,
+                                  double* __restrict__ K, long long ld, int mirror) {
+  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n) return;
+  const int i = pairs[2 * t], j = pairs[2 * t + 1];
+  if (i < 0) return;  // padding entry of an all-gathered list
+  const double v = vals[t];
+  K[(long long)j * ld + i] = v;
+  if (mirror) K[(long long)i * ld + j] = v;
+}
+
+// self-test: C[16x16] = sum_{k<16} P[k][m] * Q[k][n] with the fragment maps used above
+__global__ void qk_selftest_kernel(const double* __restrict__ P, const double* __restrict__ Q, double* __restrict__ C) {
+  const int lane = threadIdx.x & 63, j = lane & 15, q = lane >> 4;
+  v4d acc = {0, 0, 0, 0};
+  for (int ks = 0; ks < 4; ++ks) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(P[(4 * ks + q) * 16 + j], Q[(4 * ks + q) * 16 + j], acc, 0, 0, 0);
+  for (int r = 0; r < 4; ++r) C[(q + 4 * r) * 16 + j] = acc[r];
+}
+
+// ----------------------------------------------------------------------------------------
+// host API
+// ----------------------------------------------------------------------------------------
+extern "C" int qk_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+extern "C" int qk_ctx_create(int device_id, qk_ctx** out) {
+  if (!out) return fail(QK_EINVAL, "qk_ctx_create: null out");
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess || n <= 0)
+    return fail(QK_EDEVICE, "qk_ctx_create: no HIP device available (%s); this engine has no CPU fallback",
+                e == hipSuccess ? "device count is 0" : hipGetErrorString(e));
+  if (device_id < 0 || device_id >= n) return fail(QK_EINVAL, "qk_ctx_create: device %d out of range [0,%d)", device_id, n);
+  HIP_TRY(hipSetDevice(device_id));
+  hipDeviceProp_t prop;
+  HIP_TRY(hipGetDeviceProperties(&prop, device_id));
+  if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+    return fail(QK_EDEVICE, "qk_ctx_create: device %d is %s; this library is built for gfx950 only", device_id, prop.gcnArchName);
+  qk_ctx* c = new (std::nothrow) qk_ctx;
+  if (!c) return fail(QK_ENOMEM, "qk_ctx_create: out of memory");
+  c->device = device_id;
+  c->num_cus = prop.multiProcessorCount;
+  HIP_TRY(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
+  c->stream = c->own_stream;
+  HIP_TRY(hipEventCreate(&c->ev0));
+  HIP_TRY(hipEventCreate(&c->ev1));
+  HIP_TRY(hipMalloc(&c->counter, sizeof(unsigned long long)));
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(qk_sweep_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES));
+  *out = c;
+  return QK_OK;
+}
+
+extern "C" int qk_ctx_destroy(qk_ctx* c) {
+  if (!c) return QK_OK;
+  (void)hipSetDevice(c->device);
+  (void)hipStreamSynchronize(c->stream);
+  if (c->scratch) (void)hipFree(c->scratch);
+  if (c->counter) (void)hipFree(c->counter);
+  if (c->ev0) (void)hipEventDestroy(c->ev0);
+  if (c->ev1) (void)hipEventDestroy(c->ev1);
+  if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+  delete c;
+  return QK_OK;
+}
+
+extern "C" int qk_ctx_set_stream(qk_ctx* c, void* s) {
+  if (!c) return fail(QK_EINVAL, "qk_ctx_set_stream: null context");
+  c->stream = s ? reinterpret_cast<hipStream_t>(s) : c->own_stream;
+  return QK_OK;
+}
+
+extern "C" int qk_ctx_synchronize(qk_ctx* c) {
+  if (!c) return fail(QK_EINVAL, "qk_ctx_synchronize: null context");
+  HIP_TRY(hipSetDevice(c->device));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return QK_OK;
+}
+
+extern "C" int qk_mps_set_create(qk_ctx* c, int32_t n_states, int32_t n_sites, const int32_t* bond_dims,
+                                 const double* const* site_tensors, int32_t layout, qk_mps_set** out) {
+  if (!c || !out || !bond_dims || !site_tensors) return fail(QK_EINVAL, "qk_mps_set_create: null argument");
+  if (n_states <= 0 || n_sites <= 0) return fail(QK_EINVAL, "qk_mps_set_create: empty set (%d states, %d sites)", n_states, n_sites);
+  HIP_TRY(hipSetDevice(c->device));
+  const int stride = n_sites + 1;
+  std::vector<int32_t> pad((size_t)n_states * stride);
+  std::vector<int64_t> offs((size_t)n_states * n_sites);
+  std::vector<int64_t> state_off(n_states + 1, 0);
+  int max_pad = 0;
+  for (int s = 0; s < n_states; ++s) {
+    const int32_t* d = bond_dims + (size_t)s * stride;
+    if (d[0] != 1 || d[n_sites] != 1) return fail(QK_EINVAL, "qk_mps_set_create: state %d: boundary bonds must be 1", s);
+    for (int k = 0; k <= n_sites; ++k) {
+      if (d[k] <= 0) return fail(QK_EINVAL, "qk_mps_set_create: state %d: non-positive bond %d", s, k);
+      pad[(size_t)s * stride + k] = pad16(d[k]);
+      max_pad = std::max(max_pad, pad16(d[k]));
+    }
+    state_off[s + 1] = state_off[s] + qk_pack_state_size(n_sites, d);
+  }
+  qk_mps_set* m = new (std::nothrow) qk_mps_set;
+  if (!m) return fail(QK_ENOMEM, "qk_mps_set_create: out of memory");
+  m->ctx = c, m->n_states = n_states, m->n_sites = n_sites, m->max_pad = max_pad;
+  m->dims_true.assign(bond_dims, bond_dims + (size_t)n_states * stride);
+  const int64_t total = state_off[n_states];
+  m->bytes = total * (int64_t)sizeof(double);
+  hipError_t e = hipMalloc(&m->d_data, (size_t)m->bytes);
+  if (e != hipSuccess) {
+    delete m;
+    return fail(QK_EDEVICE, "qk_mps_set_create: hipMalloc of %lld bytes failed: %s", (long long)m->bytes, hipGetErrorString(e));
+  }
+  std::vector<double> stage;
+  std::vector<int64_t> so(n_sites);
+  for (int s = 0; s < n_states; ++s) {
+    const int64_t sz = state_off[s + 1] - state_off[s];
+    stage.resize((size_t)sz);
+    int rc = qk_pack_state(n_sites, bond_dims + (size_t)s * stride, site_tensors + (size_t)s * n_sites, layout, stage.data(), so.data());
+    if (rc != QK_OK) {
+      (void)hipFree(m->d_data);
+      delete m;
+      return rc;
+    }
+    for (int k = 0; k < n_sites; ++k) offs[(size_t)s * n_sites + k] = state_off[s] + so[k];
+    e = hipMemcpy(m->d_data + state_off[s], stage.data(), (size_t)sz * sizeof(double), hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+      (void)hipFree(m->d_data);
+      delete m;
+      return fail(QK_EDEVICE, "qk_mps_set_create: upload failed: %s", hipGetErrorString(e));
+    }
+  }
+  HIP_TRY(hipMalloc(&m->d_dims, pad.size() * sizeof(int32_t)));
+  HIP_TRY(hipMalloc(&m->d_offs, offs.size() * sizeof(int64_t)));
+  HIP_TRY(hipMemcpy(m->d_dims, pad.data(), pad.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(m->d_offs, offs.data(), offs.size() * sizeof(int64_t), hipMemcpyHostToDevice));
+  *out = m;
+  return QK_OK;
+}
+
+extern "C" int qk_mps_set_destroy(qk_mps_set* m) {
+  if (!m) return QK_OK;
+  (void)hipSetDevice(m->ctx->device);
+  (void)hipStreamSynchronize(m->ctx->stream);
+  if (m->d_data) (void)hipFree(m->d_data);
+  if (m->d_dims) (void)hipFree(m->d_dims);
+  if (m->d_offs) (void)hipFree(m->d_offs);
+  delete m;
+  return QK_OK;
+}
+
+extern "C" int qk_mps_set_info(const qk_mps_set* m, int32_t* n_states, int32_t* n_sites, int32_t* max_padded_bond, int64_t* device_bytes) {
+  if (!m) return fail(QK_EINVAL, "qk_mps_set_info: null set");
+  if (n_states) *n_states = m->n_states;
+  if (n_sites) *n_sites = m->n_sites;
+  if (max_padded_bond) *max_padded_bond = m->max_pad;
+  if (device_bytes) *device_bytes = m->bytes;
+  return QK_OK;
+}
+
+static int ensure_plan_uploaded(qk_ctx* c, qk_plan* p) {
+  if (p->d_pairs && p->up_ctx == c) return QK_OK;
+  if (p->d_pairs) {
+    (void)hipFree(p->d_pairs);
+    p->d_pairs = nullptr;
+  }
+  if (p->pairs.empty()) return QK_OK;
+  HIP_TRY(hipMalloc(&p->d_pairs, p->pairs.size() * sizeof(int32_t)));
+  HIP_TRY(hipMemcpy(p->d_pairs, p->pairs.data(), p->pairs.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+  p->up_ctx = c;
+  return QK_OK;
+}
+
+extern "C" int qk_gram_values(qk_ctx* c, const qk_mps_set* xs, const qk_mps_set* ys, const qk_plan* plan_c, double* values_dev, double* z_dev) {
+  if (!c || !xs || !plan_c || !values_dev) return fail(QK_EINVAL, "qk_gram_values: null argument");
+  qk_plan* plan = const_cast<qk_plan*>(plan_c);
+  if (!ys) ys = xs;
+  if (xs->ctx != c || ys->ctx != c) return fail(QK_EINVAL, "qk_gram_values: sets belong to another context");
+  if (xs->n_sites != ys->n_sites || xs->n_sites != plan->n_sites) return fail(QK_EINVAL, "qk_gram_values: site counts differ (%d, %d, plan %d)", xs->n_sites, ys->n_sites, plan->n_sites);
+  if (plan->nx != xs->n_states || plan->ny != ys->n_states) return fail(QK_EINVAL, "qk_gram_values: plan is for %dx%d states, sets hold %dx%d", plan->nx, plan->ny, xs->n_states, ys->n_states);
+  HIP_TRY(hipSetDevice(c->device));
+  const long long np = (long long)plan->pairs.size() / 2;
+  c->last = plan->stats;
+  c->last.max_bond = std::max(xs->max_pad, ys->max_pad);
+  c->last.kernel_ms = 0;
+  c->last.grid = 0;
+  if (np == 0) return QK_OK;
+  int rc = ensure_plan_uploaded(c, plan);
+  if (rc != QK_OK) return rc;
+
+  const long long x_plane = (long long)xs->max_pad * ys->max_pad;
+  const long long t_plane = 2 * x_plane;
+  const int grid = (int)std::min<long long>(np, 2ll * c->num_cus);
+  const size_t need = (size_t)grid * 2 * (size_t)(x_plane + t_plane) * sizeof(double);
+  if (need > c->scratch_bytes) {
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (c->scratch) HIP_TRY(hipFree(c->scratch));
+    c->scratch = nullptr, c->scratch_bytes = 0;
+    HIP_TRY(hipMalloc(&c->scratch, need));
+    c->scratch_bytes = need;
+  }
+  SweepArgs a;
+  a.xdata = xs->d_data, a.xdims = xs->d_dims, a.xoffs = xs->d_offs;
+  a.ydata = ys->d_data, a.ydims = ys->d_dims, a.yoffs = ys->d_offs;
+  a.n_sites = xs->n_sites;
+  a.pairs = plan->d_pairs, a.npairs = np;
+  a.values = values_dev, a.z = z_dev;
+  a.scratch = c->scratch, a.x_plane = x_plane, a.t_plane = t_plane;
+  a.counter = c->counter;
+  HIP_TRY(hipMemsetAsync(c->counter, 0, sizeof(unsigned long long), c->stream));
+  HIP_TRY(hipEventRecord(c->ev0, c->stream));
+  hipLaunchKernelGGL(qk_sweep_kernel, dim3(grid), dim3(WG_THREADS), LDS_BYTES, c->stream, a);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipEventRecord(c->ev1, c->stream));
+  c->ev_pending = true;
+  c->last.grid = grid;
+  return QK_OK;
+}
+
+extern "C" int qk_scatter(qk_ctx* c, const int32_t* pairs_dev, const double* values_dev, int64_t n, double* k_dev, int64_t ld, int32_t mirror) {
+  if (!c || !pairs_dev || !values_dev || !k_dev) return fail(QK_EINVAL, "qk_scatter: null argument");
+  if (n <= 0) return QK_OK;
+  HIP_TRY(hipSetDevice(c->device));
+  const int bs = 256;
+  hipLaunchKernelGGL(qk_scatter_kernel, dim3((unsigned)((n + bs - 1) / bs)), dim3(bs), 0, c->stream, pairs_dev, values_dev, (long long)n, k_dev, (long long)ld, (int)mirror);
+  HIP_TRY(hipGetLastError());
+  return QK_OK;
+}
+
+extern "C" int qk_get_stats(qk_ctx* c, qk_stats* out) {
+  if (!c || !out) return fail(QK_EINVAL, "qk_get_stats: null argument");
+  if (c->ev_pending) {
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipEventSynchronize(c->ev1));
+    float ms = 0;
+    HIP_TRY(hipEventElapsedTime(&ms, c->ev0, c->ev1));
+    c->last.kernel_ms = ms;
+    c->ev_pending = false;
+  }
+  *out = c->last;
+  return QK_OK;
+}
+
+// dims table of a set as the planner wants it
+static int plan_for_sets(const qk_mps_set* xs, const qk_mps_set* ys, qk_plan** plan) {
+  const bool sym = (ys == nullptr || ys == xs);
+  return qk_plan_create(xs->n_sites, xs->n_states, xs->dims_true.data(), sym ? xs->n_states : ys->n_states,
+                        sym ? nullptr : ys->dims_true.data(), sym ? QK_PLAN_SYMMETRIC : 0u, 1, 0, 16, plan);
+}
+
+extern "C" int qk_gram_host(qk_ctx* c, const qk_mps_set* xs, const qk_mps_set* ys, double* out, int64_t ld) {
+  if (!c || !xs || !out) return fail(QK_EINVAL, "qk_gram_host: null argument");
+  const bool sym = (ys == nullptr || ys == xs);
+  const int nx = xs->n_states, ny = sym ? nx : ys->n_states;
+  if (ld < nx) return fail(QK_EINVAL, "qk_gram_host: ld %lld < %d columns", (long long)ld, nx);
+  qk_plan* plan = nullptr;
+  int rc = plan_for_sets(xs, ys, &plan);
+  if (rc != QK_OK) return rc;
+  const int64_t np = qk_plan_num_pairs(plan);
+  double *d_vals = nullptr, *d_k = nullptr;
+  HIP_TRY(hipSetDevice(c->device));
+  HIP_TRY(hipMalloc(&d_vals, (size_t)np * sizeof(double)));
+  HIP_TRY(hipMalloc(&d_k, (size_t)ny * nx * sizeof(double)));
+  HIP_TRY(hipMemsetAsync(d_k, 0, (size_t)ny * nx * sizeof(double), c->stream));
+  rc = qk_gram_values(c, xs, ys, plan, d_vals, nullptr);
+  if (rc == QK_OK) rc = qk_scatter(c, plan->d_pairs, d_vals, np, d_k, nx, sym ? 1 : 0);
+  if (rc == QK_OK) {
+    hipError_t e = hipMemcpy2DAsync(out, (size_t)ld * sizeof(double), d_k, (size_t)nx * sizeof(double), (size_t)nx * sizeof(double), (size_t)ny, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e != hipSuccess) rc = fail(QK_EDEVICE, "qk_gram_host: copy back failed: %s", hipGetErrorString(e));
+  }
+  (void)hipFree(d_vals);
+  (void)hipFree(d_k);
+  qk_plan_destroy(plan);
+  return rc;
+}
+
+extern "C" int qk_overlaps_host(qk_ctx* c, const qk_mps_set* xs, const qk_mps_set* ys, double* out) {
+  if (!c || !xs || !out) return fail(QK_EINVAL, "qk_overlaps_host: null argument");
+  if (!ys) ys = xs;
+  const int nx = xs->n_states, ny = ys->n_states;
+  qk_plan* plan = nullptr;  // all ny*nx pairs (no symmetry: z[i][j] = conj z[j][i] is left to the caller)
+  int rc = qk_plan_create(xs->n_sites, nx, xs->dims_true.data(), ny, ys->dims_true.data(), 0u, 1, 0, 16, &plan);
+  if (rc != QK_OK) return rc;
+  const int64_t np = qk_plan_num_pairs(plan);
+  double *d_vals = nullptr, *d_z = nullptr;
+  HIP_TRY(hipSetDevice(c->device));
+  HIP_TRY(hipMalloc(&d_vals, (size_t)np * sizeof(double)));
+  HIP_TRY(hipMalloc(&d_z, (size_t)np * 2 * sizeof(double)));
+  rc = qk_gram_values(c, xs, ys, plan, d_vals, d_z);
+  std::vector<double> z((size_t)np * 2);
+  if (rc == QK_OK) {
+    hipError_t e = hipMemcpyAsync(z.data(), d_z, z.size() * sizeof(double), hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e != hipSuccess) rc = fail(QK_EDEVICE, "qk_overlaps_host: copy back failed: %s", hipGetErrorString(e));
+  }
+  if (rc == QK_OK) {
+    const int32_t* pr = qk_plan_pairs(plan);
+    for (int64_t t = 0; t < np; ++t) {
+      const int64_t o = ((int64_t)pr[2 * t + 1] * nx + pr[2 * t]) * 2;
+      out[o] = z[2 * t], out[o + 1] = z[2 * t + 1];
+    }
+  }
+  (void)hipFree(d_vals);
+  (void)hipFree(d_z);
+  qk_plan_destroy(plan);
+  return rc;
+}
+
+extern "C" int qk_selftest_mfma(qk_ctx* c) {
+  if (!c) return fail(QK_EINVAL, "qk_selftest_mfma: null context");
+  HIP_TRY(hipSetDevice(c->device));
+  double hp[256], hq[256], hc[256], ref[256];
+  for (int k = 0; k < 16; ++k)
+    for (int m = 0; m < 16; ++m) {
+      hp[k * 16 + m] = 1.0 + 0.25 * k - 0.5 * m + 0.125 * ((k * 7 + m * 3) % 5);  // asymmetric on purpose
+      hq[k * 16 + m] = -2.0 + 0.5 * k + 0.75 * m - 0.25 * ((k * 5 + m * 11) % 7);
+    }
+  for (int m = 0; m < 16; ++m)
+    for (int n = 0; n < 16; ++n) {
+      double s = 0;
+      for (int k = 0; k < 16; ++k) s += hp[k * 16 + m] * hq[k * 16 + n];
+      ref[m * 16 + n] = s;
+    }
+  double *dp, *dq, *dc;
+  HIP_TRY(hipMalloc(&dp, sizeof hp));
+  HIP_TRY(hipMalloc(&dq, sizeof hq));
+  HIP_TRY(hipMalloc(&dc, sizeof hc));
+  HIP_TRY(hipMemcpy(dp, hp, sizeof hp, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(dq, hq, sizeof hq, hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(qk_selftest_kernel, dim3(1), dim3(64), 0, c->stream, dp, dq, dc);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  HIP_TRY(hipMemcpy(hc, dc, sizeof hc, hipMemcpyDeviceToHost));
+  (void)hipFree(dp), (void)hipFree(dq), (void)hipFree(dc);
+  double worst = 0;
+  for (int e = 0; e < 256; ++e) worst = std::max(worst, std::fabs(hc[e] - ref[e]));
+  if (worst > 1e-9) return fail(QK_EDEVICE, "qk_selftest_mfma: f64 MFMA fragment map mismatch (max abs error %.3g)", worst);
+  return QK_OK;
+}

@@ -1,0 +1,316 @@
+"""ctypes binding of the C ABI in ``include/qkgram.h`` (library: ``libqkgram.so``, built in-tree
+by ``__graft_entry__.build()``).
+
+This is the only door to the hot path.  There is no CPU fallback: if the library
+is missing, or no gfx950 device is usable, every entry point raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from contextlib import contextmanager
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libqkgram.so")
+
+QK_LAYOUT_LPR, QK_LAYOUT_LRP = 0, 1
+QK_PLAN_SYMMETRIC = 1
+
+
+class QkError(RuntimeError):
+    pass
+
+
+class QkStats(C.Structure):
+    _fields_ = [
+        ("pairs", C.c_int64),
+        ("flops", C.c_double),
+        ("padded_flops", C.c_double),
+        ("bytes", C.c_double),
+        ("kernel_ms", C.c_double),
+        ("grid", C.c_int32),
+        ("max_bond", C.c_int32),
+    ]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
+_lib = None
+
+# every symbol include/qkgram.h declares: (name, restype, argtypes)
+_P = C.c_void_p
+_SIGNATURES = [
+    ("qk_last_error", C.c_char_p, []),
+    ("qk_device_count", C.c_int, []),
+    ("qk_ctx_create", C.c_int, [C.c_int, C.POINTER(_P)]),
+    ("qk_ctx_destroy", C.c_int, [_P]),
+    ("qk_ctx_set_stream", C.c_int, [_P, _P]),
+    ("qk_ctx_synchronize", C.c_int, [_P]),
+    ("qk_mps_set_create", C.c_int, [_P, C.c_int32, C.c_int32, _P, _P, C.c_int32, C.POINTER(_P)]),
+    ("qk_mps_set_destroy", C.c_int, [_P]),
+    ("qk_mps_set_info", C.c_int, [_P, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int64)]),
+    ("qk_pack_state_size", C.c_int64, [C.c_int32, _P]),
+    ("qk_pack_state", C.c_int, [C.c_int32, _P, _P, C.c_int32, _P, _P]),
+    ("qk_plan_create", C.c_int, [C.c_int32, C.c_int32, _P, C.c_int32, _P, C.c_uint32, C.c_int32, C.c_int32, C.c_int32, C.POINTER(_P)]),
+    ("qk_plan_destroy", C.c_int, [_P]),
+    ("qk_plan_num_pairs", C.c_int64, [_P]),
+    ("qk_plan_total_pairs", C.c_int64, [_P]),
+    ("qk_plan_max_pairs_per_rank", C.c_int64, [_P]),
+    ("qk_plan_pairs", _P, [_P]),
+    ("qk_plan_stats", C.c_int, [_P, C.POINTER(QkStats)]),
+    ("qk_gram_values", C.c_int, [_P, _P, _P, _P, _P, _P]),
+    ("qk_scatter", C.c_int, [_P, _P, _P, C.c_int64, _P, C.c_int64, C.c_int32]),
+    ("qk_gram_host", C.c_int, [_P, _P, _P, _P, C.c_int64]),
+    ("qk_overlaps_host", C.c_int, [_P, _P, _P, _P]),
+    ("qk_get_stats", C.c_int, [_P, C.POINTER(QkStats)]),
+    ("qk_selftest_mfma", C.c_int, [_P]),
+]
+EXPORTED_SYMBOLS = [s[0] for s in _SIGNATURES]
+
+
+def lib():
+    """Load ``libqkgram.so`` (once).  Raises ``QkError`` if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise QkError(
+                f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc --offload-arch=gfx950).  There is no CPU fallback for the Gram path."
+            )
+        L = C.CDLL(LIB_PATH)
+        for name, res, args in _SIGNATURES:
+            f = getattr(L, name)
+            f.restype, f.argtypes = res, args
+        _lib = L
+    return _lib
+
+
+def _check(rc: int, what: str):
+    if rc != 0:
+        msg = lib().qk_last_error()
+        raise QkError(f"{what}: error {rc}: {msg.decode() if msg else '?'}")
+
+
+def device_count() -> int:
+    return int(lib().qk_device_count())
+
+
+def _dims_table(states) -> np.ndarray:
+    return np.ascontiguousarray(np.stack([np.asarray(m.bond_dims(), dtype=np.int32) for m in states]))
+
+
+def pack_state(mps, layout=QK_LAYOUT_LPR):
+    """Host-only: the padded split-plane image of one MPS and its per-site offsets."""
+    L = lib()
+    dims = np.ascontiguousarray(mps.bond_dims(), dtype=np.int32)
+    n = len(mps)
+    tens = [np.ascontiguousarray(t, dtype=np.complex128) for t in mps.tensors]
+    ptrs = (C.c_void_p * n)(*[t.ctypes.data for t in tens])
+    size = L.qk_pack_state_size(n, dims.ctypes.data)
+    out = np.empty(size, dtype=np.float64)
+    offs = np.empty(n, dtype=np.int64)
+    _check(L.qk_pack_state(n, dims.ctypes.data, ptrs, layout, out.ctypes.data, offs.ctypes.data), "qk_pack_state")
+    return out, offs
+
+
+class Plan:
+    """Ordered share of the Gram's (x, y) pairs for one rank (host object)."""
+
+    def __init__(self, x_dims, y_dims=None, world_size=1, rank=0, block=16):
+        L = lib()
+        xd = np.ascontiguousarray(x_dims, dtype=np.int32)
+        self.symmetric = y_dims is None
+        yd = None if self.symmetric else np.ascontiguousarray(y_dims, dtype=np.int32)
+        self.nx = xd.shape[0]
+        self.ny = self.nx if self.symmetric else yd.shape[0]
+        n_sites = xd.shape[1] - 1
+        h = _P()
+        _check(
+            L.qk_plan_create(
+                n_sites, self.nx, xd.ctypes.data, self.ny, None if yd is None else yd.ctypes.data,
+                QK_PLAN_SYMMETRIC if self.symmetric else 0, world_size, rank, block, C.byref(h),
+            ),
+            "qk_plan_create",
+        )
+        self._h = h
+        self.world_size, self.rank = world_size, rank
+
+    @property
+    def handle(self):
+        return self._h
+
+    @property
+    def num_pairs(self) -> int:
+        return int(lib().qk_plan_num_pairs(self._h))
+
+    @property
+    def total_pairs(self) -> int:
+        return int(lib().qk_plan_total_pairs(self._h))
+
+    @property
+    def max_pairs_per_rank(self) -> int:
+        return int(lib().qk_plan_max_pairs_per_rank(self._h))
+
+    def pairs(self) -> np.ndarray:
+        n = self.num_pairs
+        if n == 0:
+            return np.zeros((0, 2), dtype=np.int32)
+        ptr = lib().qk_plan_pairs(self._h)
+        buf = (C.c_int32 * (2 * n)).from_address(ptr)
+        return np.frombuffer(buf, dtype=np.int32).reshape(n, 2).copy()
+
+    def stats(self) -> dict:
+        st = QkStats()
+        _check(lib().qk_plan_stats(self._h, C.byref(st)), "qk_plan_stats")
+        return st.as_dict()
+
+    def close(self):
+        if self._h:
+            lib().qk_plan_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class MpsSet:
+    """Device-resident list of MPS (opaque handle)."""
+
+    def __init__(self, ctx, handle, dims):
+        self.ctx, self._h, self.dims = ctx, handle, dims
+
+    @property
+    def handle(self):
+        return self._h
+
+    def __len__(self):
+        return self.dims.shape[0]
+
+    def info(self) -> dict:
+        a, b, c, d = C.c_int32(), C.c_int32(), C.c_int32(), C.c_int64()
+        _check(lib().qk_mps_set_info(self._h, C.byref(a), C.byref(b), C.byref(c), C.byref(d)), "qk_mps_set_info")
+        return {"n_states": a.value, "n_sites": b.value, "max_padded_bond": c.value, "device_bytes": d.value}
+
+    def close(self):
+        if self._h:
+            lib().qk_mps_set_destroy(self._h)
+            self._h = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Context:
+    """One engine context per device (what ``CuTensorNetHandle(device_id)`` is to the reference,
+    /root/reference/gpu_backend/kernel_state_ansatz.py:213)."""
+
+    def __init__(self, device_id: int = 0):
+        h = _P()
+        _check(lib().qk_ctx_create(int(device_id), C.byref(h)), "qk_ctx_create")
+        self._h, self.device_id = h, int(device_id)
+
+    @property
+    def handle(self):
+        return self._h
+
+    def set_stream(self, hip_stream: int | None):
+        _check(lib().qk_ctx_set_stream(self._h, _P(hip_stream) if hip_stream else None), "qk_ctx_set_stream")
+
+    def synchronize(self):
+        _check(lib().qk_ctx_synchronize(self._h), "qk_ctx_synchronize")
+
+    def selftest(self):
+        _check(lib().qk_selftest_mfma(self._h), "qk_selftest_mfma")
+
+    def upload(self, states, layout=QK_LAYOUT_LPR) -> MpsSet:
+        states = list(states)
+        if not states:
+            raise QkError("cannot upload an empty list of MPS")
+        n_sites = len(states[0])
+        if any(len(m) != n_sites for m in states):
+            raise QkError("all MPS of a set must have the same number of sites")
+        dims = _dims_table(states)
+        keep = [[np.ascontiguousarray(t, dtype=np.complex128) for t in m.tensors] for m in states]
+        flat = [t.ctypes.data for ts in keep for t in ts]
+        ptrs = (C.c_void_p * len(flat))(*flat)
+        h = _P()
+        _check(
+            lib().qk_mps_set_create(self._h, len(states), n_sites, dims.ctypes.data, ptrs, layout, C.byref(h)),
+            "qk_mps_set_create",
+        )
+        return MpsSet(self, h, dims)
+
+    def gram_values(self, xset: MpsSet, yset: MpsSet | None, plan: Plan, values_ptr: int, z_ptr: int | None = None):
+        """Asynchronous: enqueue the sweep of ``plan``'s pairs; device pointers are plain addresses."""
+        _check(
+            lib().qk_gram_values(self._h, xset.handle, None if yset is None else yset.handle, plan.handle, _P(values_ptr), _P(z_ptr) if z_ptr else None),
+            "qk_gram_values",
+        )
+
+    def scatter(self, pairs_ptr: int, values_ptr: int, n: int, k_ptr: int, ld: int, mirror: bool):
+        _check(lib().qk_scatter(self._h, _P(pairs_ptr), _P(values_ptr), int(n), _P(k_ptr), int(ld), 1 if mirror else 0), "qk_scatter")
+
+    def gram(self, xset: MpsSet, yset: MpsSet | None = None) -> np.ndarray:
+        """Synchronous whole Gram: rows = Y (or X), cols = X."""
+        nx = len(xset)
+        ny = nx if yset is None else len(yset)
+        out = np.zeros((ny, nx), dtype=np.float64)
+        _check(lib().qk_gram_host(self._h, xset.handle, None if yset is None else yset.handle, out.ctypes.data, nx), "qk_gram_host")
+        return out
+
+    def overlaps(self, xset: MpsSet, yset: MpsSet | None = None) -> np.ndarray:
+        """Synchronous complex overlaps z[j, i] = <x_i|y_j>."""
+        nx = len(xset)
+        ny = nx if yset is None else len(yset)
+        out = np.zeros((ny, nx, 2), dtype=np.float64)
+        _check(lib().qk_overlaps_host(self._h, xset.handle, None if yset is None else yset.handle, out.ctypes.data), "qk_overlaps_host")
+        return out[..., 0] + 1j * out[..., 1]
+
+    def stats(self) -> dict:
+        st = QkStats()
+        _check(lib().qk_get_stats(self._h, C.byref(st)), "qk_get_stats")
+        return st.as_dict()
+
+    def close(self):
+        if self._h:
+            lib().qk_ctx_destroy(self._h)
+            self._h = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+
+_default_ctx: dict[int, Context] = {}
+
+
+def default_context(device_id: int = 0) -> Context:
+    if device_id not in _default_ctx:
+        _default_ctx[device_id] = Context(device_id)
+    return _default_ctx[device_id]
+
+
+@contextmanager
+def context(device_id: int = 0):
+    ctx = Context(device_id)
+    try:
+        yield ctx
+    finally:
+        ctx.close()

@@ -1,0 +1,194 @@
+"""Matrix-product states: the container that crosses the hot-path boundary, and the
+host-side builder that produces the path's inputs.
+
+``MPS`` mirrors what the reference uses of pytket-cutensornet's MPS object
+(/root/reference/gpu_backend/kernel_state_ansatz.py:223,290,295-296,370,374,380):
+``tensors``, ``get_virtual_dimensions``, ``fidelity``, ``copy``,
+``update_libhandle``, ``len`` and ``vdot``.  Site tensors are complex128 numpy
+arrays indexed ``[left bond, physical, right bond]``.
+
+``simulate`` is the *input producer* (SURVEY.md section 8, row A8 / N1), not the hot
+path: it applies the bound gate program to |0...0> gate by gate with one SVD per
+two-qubit gate, truncating at ``truncation_fidelity`` exactly where the reference
+does (ref :141-144, :221; criterion as ITensors ``cutoff``,
+/root/reference/KernelPkg/src/KernelPkg.jl:68).  It runs on the host (LAPACK); a
+device builder is the next row of the scope table.
+"""
+from __future__ import annotations
+
+import numpy as np
+from scipy.linalg import qr as _qr
+from scipy.linalg import svd as _svd
+
+from .ansatz import OP_H, OP_RZ, OP_SWAP, OP_XX, BoundCircuit
+
+_SQRT_HALF = 0.7071067811865476
+
+
+class MPS:
+    """n-site matrix-product state, open boundaries, physical dimension 2."""
+
+    __slots__ = ("tensors", "fidelity", "_handle")
+
+    def __init__(self, tensors, fidelity: float = 1.0):
+        self.tensors = list(tensors)
+        self.fidelity = float(fidelity)
+        self._handle = None
+        left = 1
+        for k, t in enumerate(self.tensors):
+            if t.ndim != 3 or t.shape[1] != 2 or t.shape[0] != left:
+                raise RuntimeError(f"site {k}: tensor shape {t.shape} does not chain (left bond {left}, physical 2)")
+            left = t.shape[2]
+        if left != 1:
+            raise RuntimeError("the last right bond must have dimension 1")
+
+    def __len__(self) -> int:
+        return len(self.tensors)
+
+    def get_virtual_dimensions(self, position: int) -> tuple[int, int]:
+        t = self.tensors[position]
+        return (t.shape[0], t.shape[2])
+
+    def bond_dims(self) -> np.ndarray:
+        """chi[0..n]: chi[0] = chi[n] = 1."""
+        return np.asarray([1] + [t.shape[2] for t in self.tensors], dtype=np.int32)
+
+    def max_bond(self) -> int:
+        return int(self.bond_dims().max())
+
+    def nbytes(self) -> int:
+        return int(sum(t.nbytes for t in self.tensors))
+
+    def copy(self) -> "MPS":
+        return MPS([t.copy() for t in self.tensors], self.fidelity)
+
+    def update_libhandle(self, handle) -> None:
+        """Accepted for interface parity (ref :370,:374); states are immutable host
+        arrays here and device residency is owned by the engine's MPS sets."""
+        self._handle = handle
+
+    def vdot(self, other: "MPS") -> complex:
+        """<self|other> through the HIP engine (single pair; the Gram path is batch-first)."""
+        from .engine import default_context
+
+        if len(other) != len(self):
+            raise RuntimeError("the two MPS must have the same number of sites")
+        ctx = default_context()
+        with ctx.upload([self]) as xs, ctx.upload([other]) as ys:
+            return complex(ctx.overlaps(xs, ys)[0, 0])
+
+
+def random_mps(n_sites: int, bond_dims, rng) -> MPS:
+    """Random normalised MPS with a prescribed bond profile ``bond_dims[0..n]`` (pure-kernel
+    benchmark inputs): complex Gaussian tensors, right-orthonormalised by QR."""
+    chi = [int(c) for c in bond_dims]
+    assert len(chi) == n_sites + 1 and chi[0] == 1 and chi[-1] == 1
+    ts = [
+        (rng.standard_normal((chi[k], 2, chi[k + 1])) + 1j * rng.standard_normal((chi[k], 2, chi[k + 1])))
+        for k in range(n_sites)
+    ]
+    for k in range(n_sites - 1, 0, -1):
+        l, _, r = ts[k].shape
+        q, rr = np.linalg.qr(ts[k].reshape(l, 2 * r).T)  # (2r, l) = q (2r, m) rr (m, l)
+        m = q.shape[1]
+        if m != l:
+            raise ValueError(f"bond {k}: dimension {l} exceeds what its neighbours allow ({m})")
+        ts[k] = q.T.reshape(l, 2, r)
+        ts[k - 1] = np.tensordot(ts[k - 1], rr.T, axes=(2, 0))
+    ts[0] = ts[0] / np.linalg.norm(ts[0])
+    return MPS(ts)
+
+
+def _kept(s: np.ndarray, discard_budget: float, zero: float) -> tuple[int, float]:
+    """How many leading singular values survive, and the kept fraction of the weight.
+
+    Values <= ``zero`` (absolute; the state is normalised) are dropped first, then the
+    smallest values are dropped while their summed weight stays within
+    ``discard_budget`` of the total -- both sums accumulated from the small end.
+    """
+    w = s * s
+    total = float(w.sum())
+    keep = int(np.count_nonzero(s > zero))
+    keep = max(keep, 1)
+    tail = np.cumsum(w[:keep][::-1])  # tail[m-1] = weight of the m smallest candidates
+    drop = int(np.searchsorted(tail, discard_budget * total, side="right"))
+    keep = max(keep - drop, 1)
+    return keep, float(w[:keep].sum()) / total
+
+
+def simulate(circuit: BoundCircuit, truncation_fidelity: float = 1.0 - 1e-16, value_of_zero: float = 1e-16) -> MPS:
+    """MPS of circuit|0...0>, "MPSxGate" style: one SVD per two-qubit gate (ref :221)."""
+    n = circuit.n_qubits
+    budget = max(0.0, 1.0 - float(truncation_fidelity))
+    A = []
+    for _ in range(n):
+        t = np.zeros((1, 2, 1), dtype=np.complex128)
+        t[0, 0, 0] = 1.0
+        A.append(t)
+    ops = circuit.op.tolist()
+    qs = circuit.q0.tolist()
+    alphas = circuit.alpha.tolist()
+    two_q_pos = [q for o, q in zip(ops, qs) if o in (OP_XX, OP_SWAP)]
+    fidelity = 1.0
+    centre = 0  # sites < centre are left-orthonormal, sites > centre right-orthonormal
+    g2 = 0  # running index into two_q_pos
+
+    for o, q, a in zip(ops, qs, alphas):
+        if o == OP_H:
+            t = A[q]
+            A[q] = np.stack((t[:, 0] + t[:, 1], t[:, 0] - t[:, 1]), axis=1) * _SQRT_HALF
+            continue
+        if o == OP_RZ:
+            th = 0.5 * np.pi * a
+            ph = complex(np.cos(th), np.sin(th))
+            t = A[q].copy()
+            t[:, 0] *= ph.conjugate()
+            t[:, 1] *= ph
+            A[q] = t
+            continue
+
+        # ---- two-qubit gate on (q, q+1): bring the orthogonality centre onto the pair
+        while centre < q:
+            l, _, r = A[centre].shape
+            qq, rr = _qr(A[centre].reshape(l * 2, r), mode="economic", check_finite=False)
+            A[centre] = qq.reshape(l, 2, -1)
+            A[centre + 1] = np.tensordot(rr, A[centre + 1], axes=(1, 0))
+            centre += 1
+        while centre > q + 1:
+            l, _, r = A[centre].shape
+            qq, rr = _qr(A[centre].reshape(l, 2 * r).T, mode="economic", check_finite=False)
+            A[centre] = qq.T.reshape(-1, 2, r)
+            A[centre - 1] = np.tensordot(A[centre - 1], rr.T, axes=(2, 0))
+            centre -= 1
+
+        l = A[q].shape[0]
+        r = A[q + 1].shape[2]
+        theta = np.tensordot(A[q], A[q + 1], axes=(2, 0))  # [l, p, p', r]
+        if o == OP_SWAP:
+            theta = theta.transpose(0, 2, 1, 3)
+        else:  # XXPhase: cos(th) 1 - i sin(th) X(x)X
+            th = 0.5 * np.pi * a
+            theta = np.cos(th) * theta - 1j * np.sin(th) * theta[:, ::-1, ::-1, :]
+        u, s, vh = _svd(
+            np.ascontiguousarray(theta).reshape(l * 2, 2 * r),
+            full_matrices=False,
+            lapack_driver="gesdd",
+            check_finite=False,
+            overwrite_a=True,
+        )
+        keep, frac = _kept(s, budget, value_of_zero)
+        fidelity *= frac
+        s = s[:keep]
+        s = s / np.sqrt(float((s * s).sum()))
+        g2 += 1
+        nxt = two_q_pos[g2] if g2 < len(two_q_pos) else q
+        if nxt >= q + 1 or (nxt == q and True):
+            # leave the centre on q+1 (also right for a repeat on the same pair)
+            A[q] = u[:, :keep].reshape(l, 2, keep)
+            A[q + 1] = (s[:, None] * vh[:keep]).reshape(keep, 2, r)
+            centre = q + 1
+        else:
+            A[q] = (u[:, :keep] * s[None, :]).reshape(l, 2, keep)
+            A[q + 1] = vh[:keep].reshape(keep, 2, r)
+            centre = q
+    return MPS(A, fidelity)
