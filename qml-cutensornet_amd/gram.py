@@ -1,0 +1,66 @@
+"""Sharded Gram fill: the device-side replacement of the reference's tile loop, round robin
+and final reduce (/root/reference/gpu_backend/kernel_state_ansatz.py:324-428).
+
+Every rank holds all MPS on its GPU (they are small and read-only), computes its share of the
+pair list in ONE persistent kernel launch, and the shares are joined by a single RCCL
+all-gather of the packed values (the reference's ``reduce(SUM)`` of mostly-zero matrices,
+ref :428, only ever gathers).  The dense matrix is then filled on the device by a scatter
+kernel that also writes the mirrored half (ref :390-395).
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from . import engine
+
+
+class GramJob:
+    """Reusable plan + buffers for one (xset, yset) Gram on this rank's GPU."""
+
+    def __init__(self, ctx: engine.Context, xset: engine.MpsSet, yset: engine.MpsSet | None = None,
+                 world_size: int = 1, rank: int = 0, group=None, block: int = 16):
+        self.ctx, self.xset, self.yset = ctx, xset, yset
+        self.world, self.rank, self.group = int(world_size), int(rank), group
+        self.symmetric = yset is None
+        self.nx = len(xset)
+        self.ny = self.nx if self.symmetric else len(yset)
+        ydims = None if self.symmetric else yset.dims
+        self.plan = engine.Plan(xset.dims, ydims, self.world, self.rank, block)
+        self.maxp = max(1, self.plan.max_pairs_per_rank)
+        dev = torch.device("cuda", ctx.device_id)
+        self.dev = dev
+        # pair table of ALL ranks (plans are deterministic host objects), padded with -1
+        table = np.full((self.world, self.maxp, 2), -1, dtype=np.int32)
+        self.work = []
+        for r in range(self.world):
+            p = self.plan if r == self.rank else engine.Plan(xset.dims, ydims, self.world, r, block)
+            pr = p.pairs()
+            table[r, : pr.shape[0]] = pr
+            self.work.append(p.stats())
+            if p is not self.plan:
+                p.close()
+        self.all_pairs = torch.from_numpy(table.reshape(-1, 2)).to(dev)
+        self.my_vals = torch.zeros(self.maxp, dtype=torch.float64, device=dev)
+        self.all_vals = torch.zeros(self.world * self.maxp, dtype=torch.float64, device=dev) if self.world > 1 else self.my_vals
+        self.K = torch.zeros((self.ny, self.nx), dtype=torch.float64, device=dev)
+
+    def enqueue(self) -> torch.Tensor:
+        """Enqueue one full Gram on torch's current stream; returns the device matrix (async)."""
+        stream = torch.cuda.current_stream(self.dev)
+        self.ctx.set_stream(stream.cuda_stream)
+        self.ctx.gram_values(self.xset, self.yset, self.plan, self.my_vals.data_ptr())
+        if self.world > 1:
+            import torch.distributed as dist
+
+            dist.all_gather_into_tensor(self.all_vals, self.my_vals, group=self.group)
+        self.ctx.scatter(self.all_pairs.data_ptr(), self.all_vals.data_ptr(), self.all_pairs.shape[0],
+                         self.K.data_ptr(), self.nx, self.symmetric)
+        return self.K
+
+    def run(self) -> np.ndarray:
+        """One full Gram, synchronously, as a host array (rows = Y, cols = X)."""
+        return self.enqueue().cpu().numpy()
+
+    def close(self):
+        self.plan.close()
