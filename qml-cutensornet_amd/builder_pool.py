@@ -37,10 +37,22 @@ def _one(x):
 
 
 def default_workers() -> int:
+    """Host cores this process may really use: the affinity mask, clipped by the cgroup CPU
+    quota and by QK_BUILD_WORKERS (default cap 16: a GPU box hands each GPU a 16-core share
+    even though the affinity mask shows every core of the node)."""
     try:
-        return max(1, len(os.sched_getaffinity(0)))
+        n = len(os.sched_getaffinity(0))
     except AttributeError:  # pragma: no cover
-        return max(1, os.cpu_count() or 1)
+        n = os.cpu_count() or 1
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            quota, period = f.read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, -(-int(quota) // int(period))))
+    except (OSError, ValueError):
+        pass
+    cap = int(os.environ.get("QK_BUILD_WORKERS", "16"))
+    return max(1, min(n, cap))
 
 
 def build_states(ansatz, X, truncation_fidelity, workers=None):

@@ -71,6 +71,24 @@ _SIGNATURES = [
 EXPORTED_SYMBOLS = [s[0] for s in _SIGNATURES]
 
 
+def _preload_hip_runtime():
+    """One HIP runtime per process.  PyTorch-ROCm wheels bundle their own ``libamdhip64.so``
+    (SONAME libamdhip64.so.7, looked up by file name from libtorch_hip.so); libqkgram.so needs
+    ``libamdhip64.so.7``.  Loaded in the wrong order the process ends up with two runtimes and
+    the second one sees no device.  Loading torch's copy first (if torch is installed) makes
+    both resolve to the same object; without torch the system runtime is used."""
+    import importlib.util
+
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec and spec.origin:
+        cand = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+        if os.path.exists(cand):
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+
+
 def lib():
     """Load ``libqkgram.so`` (once).  Raises ``QkError`` if it has not been built."""
     global _lib
@@ -80,6 +98,7 @@ def lib():
                 f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(hipcc --offload-arch=gfx950).  There is no CPU fallback for the Gram path."
             )
+        _preload_hip_runtime()
         L = C.CDLL(LIB_PATH)
         for name, res, args in _SIGNATURES:
             f = getattr(L, name)
