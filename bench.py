@@ -102,8 +102,8 @@ def cpu_baseline(states, pairs, total_unique, npts, seconds, gpu_vals, threads):
     rng = np.random.default_rng(0)
     order = rng.permutation(pairs.shape[0])
     dims = np.stack([m.bond_dims() for m in states])
-    # choose the sample size from the algorithmic flops, assuming ~8 GFlop/s per core
-    est_rate = 8e9 * threads
+    # choose the sample size from the algorithmic flops, assuming ~20 GFlop/s per core
+    est_rate = 20e9 * threads
     chosen, acc = [], 0.0
     for t in order:
         i, j = pairs[t]
@@ -111,7 +111,7 @@ def cpu_baseline(states, pairs, total_unique, npts, seconds, gpu_vals, threads):
         f = 8 * np.minimum(a[:-1] * b[:-1] * 2 * b[1:] + 2 * a[:-1] * a[1:] * b[1:], a[:-1] * b[:-1] * 2 * a[1:] + 2 * b[:-1] * a[1:] * b[1:]).sum()
         chosen.append(t)
         acc += f
-        if acc / est_rate > seconds or len(chosen) >= 4000:
+        if acc / est_rate > seconds or len(chosen) >= 60000:
             break
     chosen = np.asarray(chosen)
     ts = [m.tensors for m in states]
