@@ -121,6 +121,11 @@ int qk_plan_stats(const qk_plan* plan, qk_stats* out); /* algorithmic flops/byte
 int qk_gram_values(qk_ctx* ctx, const qk_mps_set* xset, const qk_mps_set* yset, const qk_plan* plan,
                    double* values_dev, double* z_dev);
 
+/* Synchronous form for host communicators (mpi4py, gloo): the same sweep, values copied back
+ * into values_host[num_pairs] (and z_host[2*num_pairs] unless NULL) before returning.        */
+int qk_gram_values_host(qk_ctx* ctx, const qk_mps_set* xset, const qk_mps_set* yset, const qk_plan* plan,
+                        double* values_host, double* z_host);
+
 /* Scatter packed values into the dense matrix K (device, row-major, leading
  * dimension ld): K[j][i] = v, and K[i][j] = v as well when `mirror` != 0
  * (G:387, 390-395).  pairs_dev: [n][2] int32 on the device.                    */

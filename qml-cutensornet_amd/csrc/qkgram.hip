@@ -658,6 +658,26 @@ extern "C" int qk_gram_values(qk_ctx* c, const qk_mps_set* xs, const qk_mps_set*
   return QK_OK;
 }
 
+extern "C" int qk_gram_values_host(qk_ctx* c, const qk_mps_set* xs, const qk_mps_set* ys, const qk_plan* plan, double* values_host, double* z_host) {
+  if (!c || !plan || !values_host) return fail(QK_EINVAL, "qk_gram_values_host: null argument");
+  const int64_t np = qk_plan_num_pairs(plan);
+  if (np == 0) return QK_OK;
+  HIP_TRY(hipSetDevice(c->device));
+  double *d_vals = nullptr, *d_z = nullptr;
+  HIP_TRY(hipMalloc(&d_vals, (size_t)np * sizeof(double)));
+  if (z_host) HIP_TRY(hipMalloc(&d_z, (size_t)np * 2 * sizeof(double)));
+  int rc = qk_gram_values(c, xs, ys, plan, d_vals, d_z);
+  if (rc == QK_OK) {
+    hipError_t e = hipMemcpyAsync(values_host, d_vals, (size_t)np * sizeof(double), hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess && z_host) e = hipMemcpyAsync(z_host, d_z, (size_t)np * 2 * sizeof(double), hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e != hipSuccess) rc = fail(QK_EDEVICE, "qk_gram_values_host: copy back failed: %s", hipGetErrorString(e));
+  }
+  (void)hipFree(d_vals);
+  if (d_z) (void)hipFree(d_z);
+  return rc;
+}
+
 extern "C" int qk_scatter(qk_ctx* c, const int32_t* pairs_dev, const double* values_dev, int64_t n, double* k_dev, int64_t ld, int32_t mirror) {
   if (!c || !pairs_dev || !values_dev || !k_dev) return fail(QK_EINVAL, "qk_scatter: null argument");
   if (n <= 0) return QK_OK;

@@ -62,6 +62,7 @@ _SIGNATURES = [
     ("qk_plan_pairs", _P, [_P]),
     ("qk_plan_stats", C.c_int, [_P, C.POINTER(QkStats)]),
     ("qk_gram_values", C.c_int, [_P, _P, _P, _P, _P, _P]),
+    ("qk_gram_values_host", C.c_int, [_P, _P, _P, _P, _P, _P]),
     ("qk_scatter", C.c_int, [_P, _P, _P, C.c_int64, _P, C.c_int64, C.c_int32]),
     ("qk_gram_host", C.c_int, [_P, _P, _P, _P, C.c_int64]),
     ("qk_overlaps_host", C.c_int, [_P, _P, _P, _P]),
@@ -280,6 +281,18 @@ class Context:
             lib().qk_gram_values(self._h, xset.handle, None if yset is None else yset.handle, plan.handle, _P(values_ptr), _P(z_ptr) if z_ptr else None),
             "qk_gram_values",
         )
+
+    def gram_values_host(self, xset: MpsSet, yset: MpsSet | None, plan: Plan, want_z: bool = False):
+        """Synchronous sweep of ``plan``'s pairs; returns |z|^2 (and z if asked) as host arrays."""
+        n = plan.num_pairs
+        vals = np.zeros(n, dtype=np.float64)
+        z = np.zeros((n, 2), dtype=np.float64) if want_z else None
+        _check(
+            lib().qk_gram_values_host(self._h, xset.handle, None if yset is None else yset.handle, plan.handle,
+                                      vals.ctypes.data, None if z is None else z.ctypes.data),
+            "qk_gram_values_host",
+        )
+        return (vals, z[:, 0] + 1j * z[:, 1]) if want_z else vals
 
     def scatter(self, pairs_ptr: int, values_ptr: int, n: int, k_ptr: int, ld: int, mirror: bool):
         _check(lib().qk_scatter(self._h, _P(pairs_ptr), _P(values_ptr), int(n), _P(k_ptr), int(ld), 1 if mirror else 0), "qk_scatter")

@@ -1,0 +1,250 @@
+"""Host side of the product: circuit program, MPS builder, packing, planner, ABI surface (no GPU)."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+from helpers import golden, golden_mps_sets
+from oracle import restatement as R
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_entanglement_graph_matches_oracle():
+    from qml_cutensornet_amd import entanglement_graph
+
+    for n, d in [(2, 1), (5, 4), (8, 1), (8, 2), (13, 3), (60, 2), (100, 4)]:
+        assert entanglement_graph(n, d) == R.entanglement_graph(n, d)
+
+
+def test_circuit_program_matches_oracle_gate_list():
+    import qml_cutensornet_amd as Q
+
+    n, reps, gamma, d = 11, 3, 0.8, 4
+    X = R.synthetic_features(3, n, 3)
+    e = Q.entanglement_graph(n, d)
+    ans = Q.KernelStateAnsatz(n, reps, gamma, e)
+    assert ans.ansatz_circ.n_qubits == n
+    assert [str(s) for s in ans.feature_symbol_list] == [f"f_{i}" for i in range(n)]
+    got = ans.circuit_for_data(X[1]).as_tuples()
+    want = R.ansatz_gates(X[1], reps, gamma, e)
+    assert len(got) == len(want)
+    for (gn, gq, gp), (wn, wq, wa) in zip(got, want):
+        assert gn == wn and tuple(gq) == tuple(wq)
+        assert (not gp and wa is None) or abs(gp[0] - wa) < 1e-15
+    with pytest.raises(RuntimeError):
+        ans.circuit_for_data(X[1][:-1])
+
+
+def test_no_hadamard_and_bad_map():
+    import qml_cutensornet_amd as Q
+
+    ans = Q.KernelStateAnsatz(4, 1, 1.0, [(0, 1)], hadamard_init=False)
+    assert ans.circuit_for_data(np.ones(4)).as_tuples()[0][0] == "Rz"
+    with pytest.raises(ValueError):
+        Q.KernelStateAnsatz(4, 1, 1.0, [(0, 7)])
+
+
+@pytest.mark.parametrize("name,tol", [("cfg1_8q_r1_d1.npz", 1e-12), ("deep_10q_r3_d3.npz", 1e-8)])
+def test_builder_against_statevector_golden(name, tol):
+    import qml_cutensornet_amd as Q
+
+    g = golden(name)
+    n, reps, gamma, d = int(g["n"]), int(g["reps"]), float(g["gamma"]), int(g["d"])
+    ans = Q.KernelStateAnsatz(n, reps, gamma, Q.entanglement_graph(n, d))
+    xs = [Q.simulate(ans.circuit_for_data(x), 1 - 1e-16) for x in g["X_train"]]
+    assert all(abs(m.fidelity - 1) < 1e-12 for m in xs)
+    K = R.gram_from_mps([m.tensors for m in xs])  # oracle sweep over the product's tensors
+    assert np.abs(K - g["K_train"]).max() < tol
+    exact = [Q.simulate(ans.circuit_for_data(x), 1.0, value_of_zero=0.0) for x in g["X_train"][:3]]
+    K0 = R.gram_from_mps([m.tensors for m in exact])
+    assert np.abs(K0 - g["K_train"][:3, :3]).max() < 1e-13
+
+
+def test_truncation_keeps_fewer_bonds_and_same_values():
+    import qml_cutensornet_amd as Q
+
+    n, reps, gamma, d = 12, 3, 1.0, 3
+    X = R.synthetic_features(3, n, 4)
+    ans = Q.KernelStateAnsatz(n, reps, gamma, Q.entanglement_graph(n, d))
+    t = [Q.simulate(ans.circuit_for_data(x), 1 - 1e-16) for x in X]
+    f = [Q.simulate(ans.circuit_for_data(x), 1.0, value_of_zero=0.0) for x in X]
+    assert sum(m.max_bond() for m in t) <= sum(m.max_bond() for m in f)
+    Kt = R.gram_from_mps([m.tensors for m in t])
+    Kf = R.gram_from_mps([m.tensors for m in f])
+    assert np.abs(Kt - Kf).max() < 1e-8
+
+
+def test_mps_container_surface():
+    import qml_cutensornet_amd as Q
+
+    rng = np.random.default_rng(0)
+    m = Q.random_mps(6, [1, 2, 4, 5, 4, 2, 1], rng)
+    assert len(m) == 6 and m.get_virtual_dimensions(2) == (4, 5) and m.max_bond() == 5
+    assert abs(R.mps_inner(m.tensors, m.tensors) - 1) < 1e-13
+    c = m.copy()
+    c.tensors[0][:] = 0
+    assert np.abs(m.tensors[0]).max() > 0
+    m.update_libhandle(object())
+    with pytest.raises(RuntimeError):
+        Q.MPS([np.zeros((1, 2, 3)), np.zeros((2, 2, 1))])
+
+
+def test_builder_pool_matches_serial():
+    import qml_cutensornet_amd as Q
+    from qml_cutensornet_amd.builder_pool import build_states
+
+    n = 8
+    X = R.synthetic_features(5, n, 1)
+    ans = Q.KernelStateAnsatz(n, 2, 1.0, Q.entanglement_graph(n, 2))
+    par, secs = build_states(ans, X, 1 - 1e-16, workers=2)
+    ser = [Q.simulate(ans.circuit_for_data(x), 1 - 1e-16) for x in X]
+    assert len(secs) == 5
+    for a, b in zip(par, ser):
+        assert all(np.array_equal(s, t) for s, t in zip(a.tensors, b.tensors))
+
+
+# ---------------------------------------------------------------------------- C ABI
+def _declared_symbols():
+    text = open(os.path.join(ROOT, "include", "qkgram.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(qk_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol(built):
+    import ctypes
+
+    from qml_cutensornet_amd import engine
+
+    L = engine.lib()
+    declared = _declared_symbols()
+    assert len(declared) >= 20
+    for name in declared:
+        assert hasattr(L, name), f"{name} declared in include/qkgram.h but not exported"
+    assert sorted(engine.EXPORTED_SYMBOLS) == declared
+    raw = ctypes.CDLL(engine.LIB_PATH)
+    for name in declared:
+        getattr(raw, name)
+
+
+def test_no_gpu_means_loud_failure(built):
+    from qml_cutensornet_amd import engine
+
+    if engine.device_count() > 0:
+        pytest.skip("a GPU is present")
+    with pytest.raises(engine.QkError, match="no CPU fallback"):
+        engine.Context(0)
+    from qml_cutensornet_amd.dist import SingleComm
+    from qml_cutensornet_amd.gpu_backend.kernel_state_ansatz import build_kernel_matrix
+    import qml_cutensornet_amd as Q
+
+    ans = Q.KernelStateAnsatz(4, 1, 1.0, Q.entanglement_graph(4, 1))
+    with pytest.raises(engine.QkError):
+        build_kernel_matrix(SingleComm(), ans, np.ones((3, 4)), truncation_error=1e-16)
+
+
+def test_build_kernel_matrix_argument_errors(built):
+    from qml_cutensornet_amd.dist import SingleComm
+    from qml_cutensornet_amd.gpu_backend.kernel_state_ansatz import build_kernel_matrix
+
+    with pytest.raises(ValueError, match="X must not be smaller than Y"):
+        build_kernel_matrix(SingleComm(), None, np.zeros((2, 3)), Y=np.zeros((3, 3)), truncation_error=1e-16)
+    with pytest.raises(ValueError, match="truncation error"):
+        build_kernel_matrix(SingleComm(), None, np.zeros((2, 3)))
+
+
+def test_pack_state_layout_and_padding(built):
+    import qml_cutensornet_amd as Q
+    from qml_cutensornet_amd import engine
+
+    rng = np.random.default_rng(5)
+    m = Q.random_mps(10, [1, 2, 4, 8, 16, 17, 9, 5, 3, 2, 1], rng)
+    buf, offs = engine.pack_state(m)
+    pad = lambda c: (c + 15) // 16 * 16
+    pos = 0
+    for k, t in enumerate(m.tensors):
+        l, _, r = t.shape
+        pl, pr = pad(l), pad(r)
+        assert offs[k] == pos
+        re = buf[pos : pos + pl * 2 * pr].reshape(pl, 2, pr)
+        im = buf[pos + pl * 2 * pr : pos + 2 * pl * 2 * pr].reshape(pl, 2, pr)
+        assert np.array_equal(re[:l, :, :r], t.real) and np.array_equal(im[:l, :, :r], t.imag)
+        assert np.count_nonzero(re) <= l * 2 * r and re[l:].sum() == 0 and re[:, :, r:].sum() == 0 and im[l:].sum() == 0
+        pos += 2 * pl * 2 * pr
+    assert pos == buf.shape[0]
+    # the other host layout ([l][r][p], the order pytket-cutensornet is recalled to use) packs to the same image
+    swapped = Q.MPS(m.tensors)
+    swapped_t = [np.ascontiguousarray(t.transpose(0, 2, 1)) for t in m.tensors]
+
+    class _Fake:
+        tensors = swapped_t
+
+        def bond_dims(self):
+            return m.bond_dims()
+
+        def __len__(self):
+            return len(m)
+
+    buf2, _ = engine.pack_state(_Fake(), layout=engine.QK_LAYOUT_LRP)
+    assert np.array_equal(buf, buf2)
+
+
+@pytest.mark.parametrize("world", [1, 2, 3, 8])
+@pytest.mark.parametrize("symmetric", [True, False])
+def test_plan_partitions_the_gram(built, world, symmetric):
+    from qml_cutensornet_amd import engine
+
+    rng = np.random.default_rng(world)
+    nx, ny, n = 37, 21, 12
+    xd = np.ones((nx, n + 1), dtype=np.int32)
+    yd = np.ones((ny, n + 1), dtype=np.int32)
+    xd[:, 1:-1] = rng.integers(1, 90, size=(nx, n - 1))
+    yd[:, 1:-1] = rng.integers(1, 90, size=(ny, n - 1))
+    seen, costs, counts = set(), [], []
+    for r in range(world):
+        p = engine.Plan(xd, None if symmetric else yd, world, r, block=8)
+        pr = p.pairs()
+        st = p.stats()
+        assert st["pairs"] == len(pr) == p.num_pairs
+        assert p.total_pairs == (nx * (nx + 1) // 2 if symmetric else nx * ny)
+        for i, j in pr.tolist():
+            assert (i, j) not in seen
+            assert 0 <= i < nx and 0 <= j < (nx if symmetric else ny)
+            if symmetric:
+                assert i <= j
+            seen.add((i, j))
+        costs.append(st["padded_flops"])
+        counts.append(len(pr))
+        assert p.max_pairs_per_rank >= len(pr)
+        p.close()
+    assert len(seen) == (nx * (nx + 1) // 2 if symmetric else nx * ny)
+    assert max(counts) - min(counts) <= 1
+    if world > 1:
+        assert max(costs) / np.mean(costs) < 1.2  # the deal balances work, not only counts
+
+
+def test_plan_work_model(built):
+    from qml_cutensornet_amd import engine
+
+    a = np.array([[1, 2, 4, 3, 1]], dtype=np.int32)
+    b = np.array([[1, 2, 3, 2, 1]], dtype=np.int32)
+    st = engine.Plan(a, b).stats()
+    f = 0.0
+    for k in range(4):
+        a0, a1, b0, b1 = a[0, k], a[0, k + 1], b[0, k], b[0, k + 1]
+        f += 8 * min(a0 * b0 * 2 * b1 + 2 * a0 * a1 * b1, a0 * b0 * 2 * a1 + 2 * b0 * a1 * b1)
+    assert st["flops"] == f
+    assert st["padded_flops"] == 4 * 8 * (16 * 16 * 32 + 2 * 16 * 16 * 16)
+    assert st["bytes"] == 16 * 2 * sum(a[0, k] * a[0, k + 1] + b[0, k] * b[0, k + 1] for k in range(4)) + 8
+    with pytest.raises(engine.QkError):
+        engine.Plan(a, b, world_size=2, rank=2)
+
+
+def test_assemble_gram_host():
+    from qml_cutensornet_amd.dist import assemble_gram
+
+    K = assemble_gram(3, 3, [np.array([[0, 0], [0, 2]]), np.array([[1, 1], [1, 2], [2, 2], [0, 1]])], [np.array([1.0, 0.2]), np.array([1.0, 0.3, 1.0, 0.4])], True)
+    assert np.array_equal(K, np.array([[1, 0.4, 0.2], [0.4, 1, 0.3], [0.2, 0.3, 1]]))
+    K2 = assemble_gram(2, 3, [np.array([[0, 0], [2, 1]])], [np.array([0.5, 0.25])], False)
+    assert K2[0, 0] == 0.5 and K2[1, 2] == 0.25 and K2.sum() == 0.75
