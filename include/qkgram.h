@@ -70,8 +70,11 @@ int qk_device_count(void);
 /* ---- context --------------------------------------------------------------- */
 int qk_ctx_create(int device_id, qk_ctx** out);
 int qk_ctx_destroy(qk_ctx* ctx);
-/* run subsequent work on this hipStream_t (NULL = the context's own stream) */
+/* Run subsequent work on exactly this hipStream_t.  NULL is HIP's null (default) stream --
+ * which is what torch.cuda.current_stream().cuda_stream returns for torch's default stream.
+ * A new context starts on a private non-blocking stream; qk_ctx_use_own_stream() goes back to it. */
 int qk_ctx_set_stream(qk_ctx* ctx, void* hip_stream);
+int qk_ctx_use_own_stream(qk_ctx* ctx);
 int qk_ctx_synchronize(qk_ctx* ctx);
 
 /* ---- MPS sets ---------------------------------------------------------------

@@ -510,7 +510,13 @@ extern "C" int qk_ctx_destroy(qk_ctx* c) {
 
 extern "C" int qk_ctx_set_stream(qk_ctx* c, void* s) {
   if (!c) return fail(QK_EINVAL, "qk_ctx_set_stream: null context");
-  c->stream = s ? reinterpret_cast<hipStream_t>(s) : c->own_stream;
+  c->stream = reinterpret_cast<hipStream_t>(s);  // NULL = HIP's null stream
+  return QK_OK;
+}
+
+extern "C" int qk_ctx_use_own_stream(qk_ctx* c) {
+  if (!c) return fail(QK_EINVAL, "qk_ctx_use_own_stream: null context");
+  c->stream = c->own_stream;
   return QK_OK;
 }
 

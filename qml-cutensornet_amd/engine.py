@@ -48,6 +48,7 @@ _SIGNATURES = [
     ("qk_ctx_create", C.c_int, [C.c_int, C.POINTER(_P)]),
     ("qk_ctx_destroy", C.c_int, [_P]),
     ("qk_ctx_set_stream", C.c_int, [_P, _P]),
+    ("qk_ctx_use_own_stream", C.c_int, [_P]),
     ("qk_ctx_synchronize", C.c_int, [_P]),
     ("qk_mps_set_create", C.c_int, [_P, C.c_int32, C.c_int32, _P, _P, C.c_int32, C.POINTER(_P)]),
     ("qk_mps_set_destroy", C.c_int, [_P]),
@@ -249,7 +250,12 @@ class Context:
         return self._h
 
     def set_stream(self, hip_stream: int | None):
-        _check(lib().qk_ctx_set_stream(self._h, _P(hip_stream) if hip_stream else None), "qk_ctx_set_stream")
+        """Use exactly this hipStream_t (0 = HIP's null stream = torch's default stream); ``None``
+        goes back to the context's private stream."""
+        if hip_stream is None:
+            _check(lib().qk_ctx_use_own_stream(self._h), "qk_ctx_use_own_stream")
+        else:
+            _check(lib().qk_ctx_set_stream(self._h, _P(int(hip_stream))), "qk_ctx_set_stream")
 
     def synchronize(self):
         _check(lib().qk_ctx_synchronize(self._h), "qk_ctx_synchronize")

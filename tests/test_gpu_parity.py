@@ -155,14 +155,16 @@ def test_gram_job_device_path(gpu_ctx):
 
     rng = np.random.default_rng(21)
     xs = [Q.random_mps(12, _ragged_profile(rng, 12, 40), rng) for _ in range(9)]
-    with gpu_ctx.upload(xs) as dx:
-        job = GramJob(gpu_ctx, dx)
-        K = job.run()
-        K2 = job.run()  # re-enqueue on the same buffers
-        job.close()
+    try:
+        with gpu_ctx.upload(xs) as dx:
+            job = GramJob(gpu_ctx, dx)
+            K = job.run()  # very first launch: plan upload + scratch allocation happen here
+            K2 = job.run()  # re-enqueue on the same buffers
+            job.close()
+    finally:
+        gpu_ctx.set_stream(None)  # back to the context's private stream for the other tests
     assert np.array_equal(K, K2)
     assert np.abs(K - R.gram_from_mps([m.tensors for m in xs])).max() < TOL
-    gpu_ctx.set_stream(None)
 
 
 # ------------------------------------------------------------------ size-independent properties at benchmark scale
