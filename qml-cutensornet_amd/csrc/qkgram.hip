@@ -64,6 +64,8 @@ struct qk_ctx {
   double* scratch = nullptr;
   size_t scratch_bytes = 0;
   unsigned long long* counter = nullptr;
+  int variant = 1;     // sweep kernel variant (QK_VARIANT): 0 = v1 per-pass pipeline, 1 = flat 64x128/K8, 2 = flat 64x64/K16
+  int wgs_per_cu = 2;  // resident workgroups per CU (QK_WGS_PER_CU)
   qk_stats last{};
 };
 
@@ -72,6 +74,7 @@ struct qk_mps_set {
   int n_states = 0, n_sites = 0, max_pad = 0;
   double* d_data = nullptr;
   int32_t* d_dims = nullptr;  // padded bonds [n_states][n_sites+1]
+  int32_t* d_true = nullptr;  // true bonds   [n_states][n_sites+1]
   int64_t* d_offs = nullptr;  // re-plane offsets (doubles) [n_states][n_sites]
   std::vector<int32_t> dims_true;
   int64_t bytes = 0;
@@ -241,10 +244,12 @@ static constexpr size_t LDS_BYTES = LDS_DOUBLES * sizeof(double) + 16;  // + pai
 
 struct SweepArgs {
   const double* xdata;
-  const int32_t* xdims;
+  const int32_t* xdims;   // padded bonds
+  const int32_t* xtrue;   // true bonds
   const int64_t* xoffs;
   const double* ydata;
   const int32_t* ydims;
+  const int32_t* ytrue;
   const int64_t* yoffs;
   int n_sites;
   const int32_t* pairs;
@@ -440,6 +445,228 @@ __global__ __launch_bounds__(WG_THREADS, 2) void qk_sweep_kernel(const SweepArgs
   }
 }
 
+
+// ----------------------------------------------------------------------------------------
+// v2: flat software pipeline.  The (pass, K-tile) iteration space of one GEMM is a single
+// sequence of steps; the operands of step s+1 are fetched from global memory while step s is
+// multiplied, ACROSS pass boundaries, so only the first step of a phase exposes memory latency.
+// Output block per pass: 64 x PN complex (PN = 64 or 128), K-tiles of KTL rows, double-buffered.
+// K is walked in units of 4 (the MFMA k extent) up to the TRUE contraction length: rows beyond
+// it are zero padding and are skipped.
+// ----------------------------------------------------------------------------------------
+template <int PN, int KTL>
+struct GemmCfg {
+  static constexpr int PM = 64;
+  static constexpr int A_PLANE = KTL * PM;
+  static constexpr int B_PLANE = KTL * PN;
+  static constexpr int STAGE_D = 2 * A_PLANE + 2 * B_PLANE;  // doubles per buffer
+  static constexpr int LDS_D = 2 * STAGE_D;
+  static constexpr size_t LDS_B = (size_t)LDS_D * sizeof(double) + 16;
+  static constexpr int UA = (A_PLANE / 2) / WG_THREADS;  // 16-byte units per thread per A plane
+  static constexpr int UB = (B_PLANE / 2) / WG_THREADS;
+  static constexpr int MAXT = (PM / TILE) * (PN / TILE) / 4;  // output tiles per wave
+  static_assert(UA >= 1 && UB >= 1, "staging tile too small for 256 threads");
+};
+
+template <bool CONJB, int PN, int KTL>
+__device__ __forceinline__ void zgemm_flat(double* __restrict__ Cre, double* __restrict__ Cim, const int ldc,
+                                           const double* __restrict__ Are, const double* __restrict__ Aim, const int lda,
+                                           const double* __restrict__ Bre, const double* __restrict__ Bim, const int ldb,
+                                           const int M, const int N, const int Ktrue, double* __restrict__ lds) {
+  using G = GemmCfg<PN, KTL>;
+  constexpr int PM = G::PM;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int j = lane & 15, q = lane >> 4;
+
+  const int npm = (M + PM - 1) / PM;
+  const int npn = (N + PN - 1) / PN;
+  const int nk = (Ktrue + KTL - 1) / KTL;
+  const int k4 = (Ktrue + 3) >> 2;  // MFMA k-steps in total
+  const int total = npm * npn * nk;
+
+  double2 ra[2 * G::UA], rb[2 * G::UB];
+#pragma unroll
+  for (int i = 0; i < 2 * G::UA; ++i) ra[i] = make_double2(0.0, 0.0);
+#pragma unroll
+  for (int i = 0; i < 2 * G::UB; ++i) rb[i] = make_double2(0.0, 0.0);
+
+  // position of the step being FETCHED
+  int f_kt = 0, f_pm = 0, f_pn = 0;
+  auto fetch = [&]() __attribute__((always_inline)) {
+    const int m0 = f_pm * PM, n0 = f_pn * PN;
+    const int mcols = min(PM, M - m0), ncols = min(PN, N - n0);
+    const long long krow = (long long)f_kt * KTL;
+#pragma unroll
+    for (int i = 0; i < G::UA; ++i) {
+      const int u = tid + WG_THREADS * i;
+      const int row = u / (PM / 2), col = (u % (PM / 2)) * 2;
+      if (col < mcols) {
+        const long long o = (krow + row) * lda + m0 + col;
+        ra[2 * i] = *reinterpret_cast<const double2*>(Are + o);
+        ra[2 * i + 1] = *reinterpret_cast<const double2*>(Aim + o);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < G::UB; ++i) {
+      const int u = tid + WG_THREADS * i;
+      const int row = u / (PN / 2), col = (u % (PN / 2)) * 2;
+      if (col < ncols) {
+        const long long o = (krow + row) * ldb + n0 + col;
+        rb[2 * i] = *reinterpret_cast<const double2*>(Bre + o);
+        rb[2 * i + 1] = *reinterpret_cast<const double2*>(Bim + o);
+      }
+    }
+    if (++f_kt == nk) {
+      f_kt = 0;
+      if (++f_pm == npm) f_pm = 0, ++f_pn;
+    }
+  };
+  auto stash = [&](int buf) __attribute__((always_inline)) {
+    double* base = lds + buf * G::STAGE_D;
+#pragma unroll
+    for (int i = 0; i < G::UA; ++i) {
+      const int u = tid + WG_THREADS * i;
+      const int o = (u / (PM / 2)) * PM + (u % (PM / 2)) * 2;
+      *reinterpret_cast<double2*>(base + o) = ra[2 * i];
+      *reinterpret_cast<double2*>(base + G::A_PLANE + o) = ra[2 * i + 1];
+    }
+#pragma unroll
+    for (int i = 0; i < G::UB; ++i) {
+      const int u = tid + WG_THREADS * i;
+      const int o = (u / (PN / 2)) * PN + (u % (PN / 2)) * 2;
+      *reinterpret_cast<double2*>(base + 2 * G::A_PLANE + o) = rb[2 * i];
+      *reinterpret_cast<double2*>(base + 2 * G::A_PLANE + G::B_PLANE + o) = rb[2 * i + 1];
+    }
+  };
+
+  v4d cre[G::MAXT], cim[G::MAXT];
+  int tm[G::MAXT], tn[G::MAXT];
+  int c_kt = 0, c_pm = 0, c_pn = 0;  // position of the step being COMPUTED
+
+  fetch();
+  stash(0);
+  __syncthreads();
+  for (int s = 0; s < total; ++s) {
+    if (s + 1 < total) fetch();
+    const int m0 = c_pm * PM, n0 = c_pn * PN;
+    if (c_kt == 0) {
+      const int mt = min(PM / TILE, (M - m0) / TILE);
+      const int nt = min(PN / TILE, (N - n0) / TILE);
+      const int vt = mt * nt;
+#pragma unroll
+      for (int e = 0; e < G::MAXT; ++e) {
+        cre[e] = (v4d){0, 0, 0, 0};
+        cim[e] = (v4d){0, 0, 0, 0};
+        const int t = wave + 4 * e;
+        tm[e] = (t < vt) ? (t % mt) : -1;
+        tn[e] = (t < vt) ? (t / mt) : 0;
+      }
+    }
+    const double* base = lds + (s & 1) * G::STAGE_D;
+    const int ksteps = min(KTL / 4, k4 - c_kt * (KTL / 4));
+#pragma unroll
+    for (int e = 0; e < G::MAXT; ++e) {
+      if (tm[e] >= 0) {
+        const double* pa = base + q * PM + tm[e] * TILE + j;
+        const double* pb = base + 2 * G::A_PLANE + q * PN + tn[e] * TILE + j;
+#pragma unroll
+        for (int ks = 0; ks < KTL / 4; ++ks) {
+          if (ks < ksteps) {
+            const double ar = pa[ks * 4 * PM];
+            const double ai = pa[G::A_PLANE + ks * 4 * PM];
+            const double br = pb[ks * 4 * PN];
+            double bi = pb[G::B_PLANE + ks * 4 * PN];
+            if (CONJB) bi = -bi;
+            cre[e] = __builtin_amdgcn_mfma_f64_16x16x4f64(ar, br, cre[e], 0, 0, 0);
+            cre[e] = __builtin_amdgcn_mfma_f64_16x16x4f64(-ai, bi, cre[e], 0, 0, 0);
+            cim[e] = __builtin_amdgcn_mfma_f64_16x16x4f64(ar, bi, cim[e], 0, 0, 0);
+            cim[e] = __builtin_amdgcn_mfma_f64_16x16x4f64(ai, br, cim[e], 0, 0, 0);
+          }
+        }
+      }
+    }
+    if (c_kt == nk - 1) {
+#pragma unroll
+      for (int e = 0; e < G::MAXT; ++e) {
+        if (tm[e] >= 0) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const long long o = (long long)(m0 + tm[e] * TILE + q + 4 * r) * ldc + n0 + tn[e] * TILE + j;
+            Cre[o] = cre[e][r];
+            Cim[o] = cim[e][r];
+          }
+        }
+      }
+    }
+    if (++c_kt == nk) {
+      c_kt = 0;
+      if (++c_pm == npm) c_pm = 0, ++c_pn;
+    }
+    if (s + 1 < total) stash((s + 1) & 1);
+    __syncthreads();
+  }
+  // make this phase's output visible to the whole workgroup before the next phase reads it
+  __syncthreads();
+}
+
+template <int PN, int KTL>
+__global__ __launch_bounds__(WG_THREADS, 2) void qk_sweep_flat_kernel(const SweepArgs g) {
+  using G = GemmCfg<PN, KTL>;
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  long long* slot = reinterpret_cast<long long*>(lds + G::LDS_D);
+
+  double* Xre = g.scratch + (long long)blockIdx.x * 2 * (g.x_plane + g.t_plane);
+  double* Xim = Xre + g.x_plane;
+  double* Tre = Xim + g.x_plane;
+  double* Tim = Tre + g.t_plane;
+  const int tid = threadIdx.x;
+
+  for (;;) {
+    if (tid == 0) *slot = (long long)atomicAdd(g.counter, 1ull);
+    __syncthreads();
+    const long long p = *slot;
+    __syncthreads();
+    if (p >= g.npairs) break;
+    const int xi = g.pairs[2 * p], yj = g.pairs[2 * p + 1];
+    const int32_t* xd = g.xdims + (long long)xi * (g.n_sites + 1);
+    const int32_t* yd = g.ydims + (long long)yj * (g.n_sites + 1);
+    const int32_t* xt = g.xtrue + (long long)xi * (g.n_sites + 1);
+    const int32_t* yt = g.ytrue + (long long)yj * (g.n_sites + 1);
+    const int64_t* xo = g.xoffs + (long long)xi * g.n_sites;
+    const int64_t* yo = g.yoffs + (long long)yj * g.n_sites;
+    {
+      const int a = xd[0], b = yd[0];
+      for (int e = tid; e < a * b; e += WG_THREADS) {
+        Xre[e] = (e == 0) ? 1.0 : 0.0;
+        Xim[e] = 0.0;
+      }
+      __syncthreads();
+    }
+    for (int k = 0; k < g.n_sites; ++k) {
+      const int a = xd[k], a2 = xd[k + 1], b = yd[k], b2 = yd[k + 1];
+      const double* Are = g.xdata + xo[k];
+      const double* Aim = Are + (long long)a * 2 * a2;
+      const double* Bre = g.ydata + yo[k];
+      const double* Bim = Bre + (long long)b * 2 * b2;
+      // phase 1: T[a x 2b2] = X^T B, contraction over the TRUE bond b_k of y
+      zgemm_flat<false, PN, KTL>(Tre, Tim, 2 * b2, Xre, Xim, a, Bre, Bim, 2 * b2, a, 2 * b2, yt[k], lds);
+      // phase 2: X'[b2 x a2] = T^T conj(A), contraction over the 2 * a_k true rows (L, p)
+      zgemm_flat<true, PN, KTL>(Xre, Xim, a2, Tre, Tim, b2, Are, Aim, a2, b2, a2, 2 * xt[k], lds);
+    }
+    if (tid == 0) {
+      const double re = Xre[0], im = Xim[0];
+      g.values[p] = re * re + im * im;
+      if (g.z) {
+        g.z[2 * p] = re;
+        g.z[2 * p + 1] = im;
+      }
+    }
+    __syncthreads();
+  }
+}
+
 __global__ void qk_scatter_kernel(const int32_t* __restrict__ pairs, const double* __restrict__ vals, long long n,
                                   double* __restrict__ K, long long ld, int mirror) {
   const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -491,6 +718,10 @@ extern "C" int qk_ctx_create(int device_id, qk_ctx** out) {
   HIP_TRY(hipEventCreate(&c->ev1));
   HIP_TRY(hipMalloc(&c->counter, sizeof(unsigned long long)));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(qk_sweep_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES));
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(qk_sweep_flat_kernel<128, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)GemmCfg<128, 8>::LDS_B));
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(qk_sweep_flat_kernel<64, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)GemmCfg<64, 16>::LDS_B));
+  if (const char* v = std::getenv("QK_VARIANT")) c->variant = std::atoi(v);
+  if (const char* v = std::getenv("QK_WGS_PER_CU")) c->wgs_per_cu = std::max(1, std::min(2, std::atoi(v)));
   *out = c;
   return QK_OK;
 }
@@ -580,6 +811,8 @@ extern "C" int qk_mps_set_create(qk_ctx* c, int32_t n_states, int32_t n_sites, c
   HIP_TRY(hipMalloc(&m->d_dims, pad.size() * sizeof(int32_t)));
   HIP_TRY(hipMalloc(&m->d_offs, offs.size() * sizeof(int64_t)));
   HIP_TRY(hipMemcpy(m->d_dims, pad.data(), pad.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+  HIP_TRY(hipMalloc(&m->d_true, pad.size() * sizeof(int32_t)));
+  HIP_TRY(hipMemcpy(m->d_true, bond_dims, pad.size() * sizeof(int32_t), hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(m->d_offs, offs.data(), offs.size() * sizeof(int64_t), hipMemcpyHostToDevice));
   *out = m;
   return QK_OK;
@@ -591,6 +824,7 @@ extern "C" int qk_mps_set_destroy(qk_mps_set* m) {
   (void)hipStreamSynchronize(m->ctx->stream);
   if (m->d_data) (void)hipFree(m->d_data);
   if (m->d_dims) (void)hipFree(m->d_dims);
+  if (m->d_true) (void)hipFree(m->d_true);
   if (m->d_offs) (void)hipFree(m->d_offs);
   delete m;
   return QK_OK;
@@ -637,7 +871,7 @@ extern "C" int qk_gram_values(qk_ctx* c, const qk_mps_set* xs, const qk_mps_set*
 
   const long long x_plane = (long long)xs->max_pad * ys->max_pad;
   const long long t_plane = 2 * x_plane;
-  const int grid = (int)std::min<long long>(np, 2ll * c->num_cus);
+  const int grid = (int)std::min<long long>(np, (long long)c->wgs_per_cu * c->num_cus);
   const size_t need = (size_t)grid * 2 * (size_t)(x_plane + t_plane) * sizeof(double);
   if (need > c->scratch_bytes) {
     HIP_TRY(hipStreamSynchronize(c->stream));
@@ -647,8 +881,8 @@ extern "C" int qk_gram_values(qk_ctx* c, const qk_mps_set* xs, const qk_mps_set*
     c->scratch_bytes = need;
   }
   SweepArgs a;
-  a.xdata = xs->d_data, a.xdims = xs->d_dims, a.xoffs = xs->d_offs;
-  a.ydata = ys->d_data, a.ydims = ys->d_dims, a.yoffs = ys->d_offs;
+  a.xdata = xs->d_data, a.xdims = xs->d_dims, a.xtrue = xs->d_true, a.xoffs = xs->d_offs;
+  a.ydata = ys->d_data, a.ydims = ys->d_dims, a.ytrue = ys->d_true, a.yoffs = ys->d_offs;
   a.n_sites = xs->n_sites;
   a.pairs = plan->d_pairs, a.npairs = np;
   a.values = values_dev, a.z = z_dev;
@@ -656,7 +890,13 @@ extern "C" int qk_gram_values(qk_ctx* c, const qk_mps_set* xs, const qk_mps_set*
   a.counter = c->counter;
   HIP_TRY(hipMemsetAsync(c->counter, 0, sizeof(unsigned long long), c->stream));
   HIP_TRY(hipEventRecord(c->ev0, c->stream));
-  hipLaunchKernelGGL(qk_sweep_kernel, dim3(grid), dim3(WG_THREADS), LDS_BYTES, c->stream, a);
+  constexpr size_t lds_a = GemmCfg<128, 8>::LDS_B, lds_b = GemmCfg<64, 16>::LDS_B;
+  if (c->variant == 0)
+    qk_sweep_kernel<<<dim3(grid), dim3(WG_THREADS), LDS_BYTES, c->stream>>>(a);
+  else if (c->variant == 2)
+    qk_sweep_flat_kernel<64, 16><<<dim3(grid), dim3(WG_THREADS), lds_b, c->stream>>>(a);
+  else
+    qk_sweep_flat_kernel<128, 8><<<dim3(grid), dim3(WG_THREADS), lds_a, c->stream>>>(a);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipEventRecord(c->ev1, c->stream));
   c->ev_pending = true;
