@@ -64,7 +64,7 @@ struct qk_ctx {
   double* scratch = nullptr;
   size_t scratch_bytes = 0;
   unsigned long long* counter = nullptr;
-  int variant = 1;     // sweep kernel variant (QK_VARIANT): 0 = v1 per-pass pipeline, 1 = flat 64x128/K8, 2 = flat 64x64/K16
+  int variant = 1;     // sweep kernel variant (QK_VARIANT): 0 = v1 per-pass pipeline, 1 = flat 64x64/K8, 2 = flat 64x64/K16
   int wgs_per_cu = 2;  // resident workgroups per CU (QK_WGS_PER_CU)
   qk_stats last{};
 };
@@ -468,6 +468,35 @@ struct GemmCfg {
   static_assert(UA >= 1 && UB >= 1, "staging tile too small for 256 threads");
 };
 
+
+// Multiply one staged K-tile into this wave's accumulator tiles (the first `cnt` are valid).
+// FULLK is compile-time so that the common full K-tile is straight-line code per tile.
+template <bool CONJB, int PM, int PN, int A_PLANE, int B_PLANE, int KSTEPS, int MAXT, bool FULLK>
+__device__ __forceinline__ void mma_ktile(v4d (&cre)[MAXT], v4d (&cim)[MAXT], const int (&tm)[MAXT], const int (&tn)[MAXT],
+                                          const double* __restrict__ base, const int q, const int j, const int cnt, const int ksteps) {
+#pragma unroll
+  for (int e = 0; e < MAXT; ++e) {
+    if (e < cnt) {
+      const double* pa = base + q * PM + tm[e] * TILE + j;
+      const double* pb = base + 2 * A_PLANE + q * PN + tn[e] * TILE + j;
+#pragma unroll
+      for (int ks = 0; ks < KSTEPS; ++ks) {
+        if (FULLK || ks < ksteps) {
+          const double ar = pa[ks * 4 * PM];
+          const double ai = pa[A_PLANE + ks * 4 * PM];
+          const double br = pb[ks * 4 * PN];
+          double bi = pb[B_PLANE + ks * 4 * PN];
+          if (CONJB) bi = -bi;
+          cre[e] = __builtin_amdgcn_mfma_f64_16x16x4f64(ar, br, cre[e], 0, 0, 0);
+          cre[e] = __builtin_amdgcn_mfma_f64_16x16x4f64(-ai, bi, cre[e], 0, 0, 0);
+          cim[e] = __builtin_amdgcn_mfma_f64_16x16x4f64(ar, bi, cim[e], 0, 0, 0);
+          cim[e] = __builtin_amdgcn_mfma_f64_16x16x4f64(ai, br, cim[e], 0, 0, 0);
+        }
+      }
+    }
+  }
+}
+
 template <bool CONJB, int PN, int KTL>
 __device__ __forceinline__ void zgemm_flat(double* __restrict__ Cre, double* __restrict__ Cim, const int ldc,
                                            const double* __restrict__ Are, const double* __restrict__ Aim, const int lda,
@@ -543,6 +572,7 @@ __device__ __forceinline__ void zgemm_flat(double* __restrict__ Cre, double* __r
 
   v4d cre[G::MAXT], cim[G::MAXT];
   int tm[G::MAXT], tn[G::MAXT];
+  int cnt = 0;                       // valid output tiles of this wave in the current pass
   int c_kt = 0, c_pm = 0, c_pn = 0;  // position of the step being COMPUTED
 
   fetch();
@@ -555,42 +585,26 @@ __device__ __forceinline__ void zgemm_flat(double* __restrict__ Cre, double* __r
       const int mt = min(PM / TILE, (M - m0) / TILE);
       const int nt = min(PN / TILE, (N - n0) / TILE);
       const int vt = mt * nt;
+      cnt = (vt > wave) ? (vt - wave + 3) >> 2 : 0;  // tiles t = wave + 4e < vt
 #pragma unroll
       for (int e = 0; e < G::MAXT; ++e) {
         cre[e] = (v4d){0, 0, 0, 0};
         cim[e] = (v4d){0, 0, 0, 0};
-        const int t = wave + 4 * e;
-        tm[e] = (t < vt) ? (t % mt) : -1;
-        tn[e] = (t < vt) ? (t / mt) : 0;
+        const int t = min(wave + 4 * e, vt - 1);  // clamp: entries e >= cnt are never used
+        tm[e] = t % mt;
+        tn[e] = t / mt;
       }
     }
     const double* base = lds + (s & 1) * G::STAGE_D;
     const int ksteps = min(KTL / 4, k4 - c_kt * (KTL / 4));
-#pragma unroll
-    for (int e = 0; e < G::MAXT; ++e) {
-      if (tm[e] >= 0) {
-        const double* pa = base + q * PM + tm[e] * TILE + j;
-        const double* pb = base + 2 * G::A_PLANE + q * PN + tn[e] * TILE + j;
-#pragma unroll
-        for (int ks = 0; ks < KTL / 4; ++ks) {
-          if (ks < ksteps) {
-            const double ar = pa[ks * 4 * PM];
-            const double ai = pa[G::A_PLANE + ks * 4 * PM];
-            const double br = pb[ks * 4 * PN];
-            double bi = pb[G::B_PLANE + ks * 4 * PN];
-            if (CONJB) bi = -bi;
-            cre[e] = __builtin_amdgcn_mfma_f64_16x16x4f64(ar, br, cre[e], 0, 0, 0);
-            cre[e] = __builtin_amdgcn_mfma_f64_16x16x4f64(-ai, bi, cre[e], 0, 0, 0);
-            cim[e] = __builtin_amdgcn_mfma_f64_16x16x4f64(ar, bi, cim[e], 0, 0, 0);
-            cim[e] = __builtin_amdgcn_mfma_f64_16x16x4f64(ai, br, cim[e], 0, 0, 0);
-          }
-        }
-      }
-    }
+    if (ksteps == KTL / 4)
+      mma_ktile<CONJB, PM, PN, G::A_PLANE, G::B_PLANE, KTL / 4, G::MAXT, true>(cre, cim, tm, tn, base, q, j, cnt, ksteps);
+    else
+      mma_ktile<CONJB, PM, PN, G::A_PLANE, G::B_PLANE, KTL / 4, G::MAXT, false>(cre, cim, tm, tn, base, q, j, cnt, ksteps);
     if (c_kt == nk - 1) {
 #pragma unroll
       for (int e = 0; e < G::MAXT; ++e) {
-        if (tm[e] >= 0) {
+        if (e < cnt) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const long long o = (long long)(m0 + tm[e] * TILE + q + 4 * r) * ldc + n0 + tn[e] * TILE + j;
@@ -718,7 +732,7 @@ extern "C" int qk_ctx_create(int device_id, qk_ctx** out) {
   HIP_TRY(hipEventCreate(&c->ev1));
   HIP_TRY(hipMalloc(&c->counter, sizeof(unsigned long long)));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(qk_sweep_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES));
-  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(qk_sweep_flat_kernel<128, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)GemmCfg<128, 8>::LDS_B));
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(qk_sweep_flat_kernel<64, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)GemmCfg<64, 8>::LDS_B));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(qk_sweep_flat_kernel<64, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)GemmCfg<64, 16>::LDS_B));
   if (const char* v = std::getenv("QK_VARIANT")) c->variant = std::atoi(v);
   if (const char* v = std::getenv("QK_WGS_PER_CU")) c->wgs_per_cu = std::max(1, std::min(2, std::atoi(v)));
@@ -890,13 +904,13 @@ extern "C" int qk_gram_values(qk_ctx* c, const qk_mps_set* xs, const qk_mps_set*
   a.counter = c->counter;
   HIP_TRY(hipMemsetAsync(c->counter, 0, sizeof(unsigned long long), c->stream));
   HIP_TRY(hipEventRecord(c->ev0, c->stream));
-  constexpr size_t lds_a = GemmCfg<128, 8>::LDS_B, lds_b = GemmCfg<64, 16>::LDS_B;
+  constexpr size_t lds_a = GemmCfg<64, 8>::LDS_B, lds_b = GemmCfg<64, 16>::LDS_B;
   if (c->variant == 0)
     qk_sweep_kernel<<<dim3(grid), dim3(WG_THREADS), LDS_BYTES, c->stream>>>(a);
   else if (c->variant == 2)
     qk_sweep_flat_kernel<64, 16><<<dim3(grid), dim3(WG_THREADS), lds_b, c->stream>>>(a);
   else
-    qk_sweep_flat_kernel<128, 8><<<dim3(grid), dim3(WG_THREADS), lds_a, c->stream>>>(a);
+    qk_sweep_flat_kernel<64, 8><<<dim3(grid), dim3(WG_THREADS), lds_a, c->stream>>>(a);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipEventRecord(c->ev1, c->stream));
   c->ev_pending = true;
