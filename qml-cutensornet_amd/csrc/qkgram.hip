@@ -470,27 +470,65 @@ struct GemmCfg {
 
 
 // Multiply one staged K-tile into this wave's accumulator tiles (the first `cnt` are valid).
-// FULLK is compile-time so that the common full K-tile is straight-line code per tile.
+// Full K-tiles (the common case) run a software pipeline over "groups" of 2 k-steps: the LDS
+// fragment reads of group g+1 are issued before the 8 MFMAs of group g, so that the LDS latency
+// hides under 512 cycles of matrix work instead of stalling the wave at every group.
 template <bool CONJB, int PM, int PN, int A_PLANE, int B_PLANE, int KSTEPS, int MAXT, bool FULLK>
 __device__ __forceinline__ void mma_ktile(v4d (&cre)[MAXT], v4d (&cim)[MAXT], const int (&tm)[MAXT], const int (&tn)[MAXT],
                                           const double* __restrict__ base, const int q, const int j, const int cnt, const int ksteps) {
+  if constexpr (FULLK && (KSTEPS % 2 == 0)) {
+    constexpr int GPT = KSTEPS / 2;       // groups per tile
+    constexpr int NG = MAXT * GPT;        // groups per K-tile
+    double far[2][2], fai[2][2], fbr[2][2], fbi[2][2];  // [buffer][k-step in group]
+    auto load = [&](int g, int buf) __attribute__((always_inline)) {
+      const int e = g / GPT, k0 = (g % GPT) * 2;
+      const double* pa = base + (q + 4 * k0) * PM + tm[e] * TILE + j;
+      const double* pb = base + 2 * A_PLANE + (q + 4 * k0) * PN + tn[e] * TILE + j;
 #pragma unroll
-  for (int e = 0; e < MAXT; ++e) {
-    if (e < cnt) {
-      const double* pa = base + q * PM + tm[e] * TILE + j;
-      const double* pb = base + 2 * A_PLANE + q * PN + tn[e] * TILE + j;
+      for (int h = 0; h < 2; ++h) {
+        far[buf][h] = pa[h * 4 * PM];
+        fai[buf][h] = pa[A_PLANE + h * 4 * PM];
+        fbr[buf][h] = pb[h * 4 * PN];
+        fbi[buf][h] = CONJB ? -pb[B_PLANE + h * 4 * PN] : pb[B_PLANE + h * 4 * PN];
+      }
+    };
+    if (cnt > 0) load(0, 0);
 #pragma unroll
-      for (int ks = 0; ks < KSTEPS; ++ks) {
-        if (FULLK || ks < ksteps) {
-          const double ar = pa[ks * 4 * PM];
-          const double ai = pa[A_PLANE + ks * 4 * PM];
-          const double br = pb[ks * 4 * PN];
-          double bi = pb[B_PLANE + ks * 4 * PN];
-          if (CONJB) bi = -bi;
+    for (int g = 0; g < NG; ++g) {
+      const int e = g / GPT;
+      if (e < cnt) {
+        if (g + 1 < NG && (g + 1) / GPT < cnt) load(g + 1, (g + 1) & 1);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const double ar = far[g & 1][h], ai = fai[g & 1][h], br = fbr[g & 1][h], bi = fbi[g & 1][h];
           cre[e] = __builtin_amdgcn_mfma_f64_16x16x4f64(ar, br, cre[e], 0, 0, 0);
           cre[e] = __builtin_amdgcn_mfma_f64_16x16x4f64(-ai, bi, cre[e], 0, 0, 0);
           cim[e] = __builtin_amdgcn_mfma_f64_16x16x4f64(ar, bi, cim[e], 0, 0, 0);
           cim[e] = __builtin_amdgcn_mfma_f64_16x16x4f64(ai, br, cim[e], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+  } else {
+#pragma unroll
+    for (int e = 0; e < MAXT; ++e) {
+      if (e < cnt) {
+        const double* pa = base + q * PM + tm[e] * TILE + j;
+        const double* pb = base + 2 * A_PLANE + q * PN + tn[e] * TILE + j;
+#pragma unroll
+        for (int ks = 0; ks < KSTEPS; ++ks) {
+          if (FULLK || ks < ksteps) {
+            const double ar = pa[ks * 4 * PM];
+            const double ai = pa[A_PLANE + ks * 4 * PM];
+            const double br = pb[ks * 4 * PN];
+            double bi = pb[B_PLANE + ks * 4 * PN];
+            if (CONJB) bi = -bi;
+            cre[e] = __builtin_amdgcn_mfma_f64_16x16x4f64(ar, br, cre[e], 0, 0, 0);
+            cre[e] = __builtin_amdgcn_mfma_f64_16x16x4f64(-ai, bi, cre[e], 0, 0, 0);
+            cim[e] = __builtin_amdgcn_mfma_f64_16x16x4f64(ar, bi, cim[e], 0, 0, 0);
+            cim[e] = __builtin_amdgcn_mfma_f64_16x16x4f64(ai, br, cim[e], 0, 0, 0);
+          }
         }
       }
     }
