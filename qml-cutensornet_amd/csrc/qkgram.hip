@@ -230,6 +230,14 @@ extern "C" int qk_plan_stats(const qk_plan* p, qk_stats* out) {
 // device code
 // ----------------------------------------------------------------------------------------
 typedef double v4d __attribute__((ext_vector_type(4)));
+typedef double v2d __attribute__((ext_vector_type(2)));
+
+// 16-byte load of a streamed (read-once) operand: non-temporal so that it does not push the
+// workgroup's X/T scratch lines out of the XCD's L2
+__device__ __forceinline__ double2 load_stream(const double* p) {
+  const v2d v = __builtin_nontemporal_load(reinterpret_cast<const v2d*>(p));
+  return make_double2(v.x, v.y);
+}
 
 // Staging geometry of the complex GEMM: a workgroup (4 waves) produces one 64x64 complex
 // output block per pass; operands are staged k-major through LDS in K-tiles of 16 rows,
@@ -535,7 +543,7 @@ __device__ __forceinline__ void mma_ktile(v4d (&cre)[MAXT], v4d (&cim)[MAXT], co
   }
 }
 
-template <bool CONJB, int PN, int KTL>
+template <bool CONJB, int PN, int KTL, bool NTB>
 __device__ __forceinline__ void zgemm_flat(double* __restrict__ Cre, double* __restrict__ Cim, const int ldc,
                                            const double* __restrict__ Are, const double* __restrict__ Aim, const int lda,
                                            const double* __restrict__ Bre, const double* __restrict__ Bim, const int ldb,
@@ -581,8 +589,13 @@ __device__ __forceinline__ void zgemm_flat(double* __restrict__ Cre, double* __r
       const int row = u / (PN / 2), col = (u % (PN / 2)) * 2;
       if (col < ncols) {
         const long long o = (krow + row) * ldb + n0 + col;
-        rb[2 * i] = *reinterpret_cast<const double2*>(Bre + o);
-        rb[2 * i + 1] = *reinterpret_cast<const double2*>(Bim + o);
+        if (NTB) {
+          rb[2 * i] = load_stream(Bre + o);
+          rb[2 * i + 1] = load_stream(Bim + o);
+        } else {
+          rb[2 * i] = *reinterpret_cast<const double2*>(Bre + o);
+          rb[2 * i + 1] = *reinterpret_cast<const double2*>(Bim + o);
+        }
       }
     }
     if (++f_kt == nk) {
@@ -663,7 +676,7 @@ __device__ __forceinline__ void zgemm_flat(double* __restrict__ Cre, double* __r
   __syncthreads();
 }
 
-template <int PN, int KTL>
+template <int PN, int KTL, bool NTB>
 __global__ __launch_bounds__(WG_THREADS, 2) void qk_sweep_flat_kernel(const SweepArgs g) {
   using G = GemmCfg<PN, KTL>;
   extern __shared__ __attribute__((aligned(16))) double lds[];
@@ -703,9 +716,9 @@ __global__ __launch_bounds__(WG_THREADS, 2) void qk_sweep_flat_kernel(const Swee
       const double* Bre = g.ydata + yo[k];
       const double* Bim = Bre + (long long)b * 2 * b2;
       // phase 1: T[a x 2b2] = X^T B, contraction over the TRUE bond b_k of y
-      zgemm_flat<false, PN, KTL>(Tre, Tim, 2 * b2, Xre, Xim, a, Bre, Bim, 2 * b2, a, 2 * b2, yt[k], lds);
+      zgemm_flat<false, PN, KTL, NTB>(Tre, Tim, 2 * b2, Xre, Xim, a, Bre, Bim, 2 * b2, a, 2 * b2, yt[k], lds);
       // phase 2: X'[b2 x a2] = T^T conj(A), contraction over the 2 * a_k true rows (L, p)
-      zgemm_flat<true, PN, KTL>(Xre, Xim, a2, Tre, Tim, b2, Are, Aim, a2, b2, a2, 2 * xt[k], lds);
+      zgemm_flat<true, PN, KTL, NTB>(Xre, Xim, a2, Tre, Tim, b2, Are, Aim, a2, b2, a2, 2 * xt[k], lds);
     }
     if (tid == 0) {
       const double re = Xre[0], im = Xim[0];
@@ -770,8 +783,9 @@ extern "C" int qk_ctx_create(int device_id, qk_ctx** out) {
   HIP_TRY(hipEventCreate(&c->ev1));
   HIP_TRY(hipMalloc(&c->counter, sizeof(unsigned long long)));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(qk_sweep_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES));
-  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(qk_sweep_flat_kernel<64, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)GemmCfg<64, 8>::LDS_B));
-  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(qk_sweep_flat_kernel<64, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)GemmCfg<64, 16>::LDS_B));
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(qk_sweep_flat_kernel<64, 8, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)GemmCfg<64, 8>::LDS_B));
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(qk_sweep_flat_kernel<64, 16, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)GemmCfg<64, 16>::LDS_B));
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(qk_sweep_flat_kernel<64, 16, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)GemmCfg<64, 16>::LDS_B));
   if (const char* v = std::getenv("QK_VARIANT")) c->variant = std::atoi(v);
   if (const char* v = std::getenv("QK_WGS_PER_CU")) c->wgs_per_cu = std::max(1, std::min(2, std::atoi(v)));
   *out = c;
@@ -946,9 +960,11 @@ extern "C" int qk_gram_values(qk_ctx* c, const qk_mps_set* xs, const qk_mps_set*
   if (c->variant == 0)
     qk_sweep_kernel<<<dim3(grid), dim3(WG_THREADS), LDS_BYTES, c->stream>>>(a);
   else if (c->variant == 2)
-    qk_sweep_flat_kernel<64, 16><<<dim3(grid), dim3(WG_THREADS), lds_b, c->stream>>>(a);
+    qk_sweep_flat_kernel<64, 16, false><<<dim3(grid), dim3(WG_THREADS), lds_b, c->stream>>>(a);
+  else if (c->variant == 3)
+    qk_sweep_flat_kernel<64, 16, true><<<dim3(grid), dim3(WG_THREADS), lds_b, c->stream>>>(a);
   else
-    qk_sweep_flat_kernel<64, 8><<<dim3(grid), dim3(WG_THREADS), lds_a, c->stream>>>(a);
+    qk_sweep_flat_kernel<64, 8, false><<<dim3(grid), dim3(WG_THREADS), lds_a, c->stream>>>(a);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipEventRecord(c->ev1, c->stream));
   c->ev_pending = true;
