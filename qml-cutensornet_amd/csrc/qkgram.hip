@@ -676,8 +676,8 @@ __device__ __forceinline__ void zgemm_flat(double* __restrict__ Cre, double* __r
   __syncthreads();
 }
 
-template <int PN, int KTL, bool NTB>
-__global__ __launch_bounds__(WG_THREADS, 2) void qk_sweep_flat_kernel(const SweepArgs g) {
+template <int PN, int KTL, bool NTB, int OCC = 2>
+__global__ __launch_bounds__(WG_THREADS, OCC) void qk_sweep_flat_kernel(const SweepArgs g) {
   using G = GemmCfg<PN, KTL>;
   extern __shared__ __attribute__((aligned(16))) double lds[];
   long long* slot = reinterpret_cast<long long*>(lds + G::LDS_D);
@@ -786,8 +786,10 @@ extern "C" int qk_ctx_create(int device_id, qk_ctx** out) {
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(qk_sweep_flat_kernel<64, 8, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)GemmCfg<64, 8>::LDS_B));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(qk_sweep_flat_kernel<64, 16, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)GemmCfg<64, 16>::LDS_B));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(qk_sweep_flat_kernel<64, 16, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)GemmCfg<64, 16>::LDS_B));
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(qk_sweep_flat_kernel<64, 8, false, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)GemmCfg<64, 8>::LDS_B));
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(qk_sweep_flat_kernel<64, 8, false, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)GemmCfg<64, 8>::LDS_B));
   if (const char* v = std::getenv("QK_VARIANT")) c->variant = std::atoi(v);
-  if (const char* v = std::getenv("QK_WGS_PER_CU")) c->wgs_per_cu = std::max(1, std::min(2, std::atoi(v)));
+  if (const char* v = std::getenv("QK_WGS_PER_CU")) c->wgs_per_cu = std::max(1, std::min(4, std::atoi(v)));
   *out = c;
   return QK_OK;
 }
@@ -963,6 +965,10 @@ extern "C" int qk_gram_values(qk_ctx* c, const qk_mps_set* xs, const qk_mps_set*
     qk_sweep_flat_kernel<64, 16, false><<<dim3(grid), dim3(WG_THREADS), lds_b, c->stream>>>(a);
   else if (c->variant == 3)
     qk_sweep_flat_kernel<64, 16, true><<<dim3(grid), dim3(WG_THREADS), lds_b, c->stream>>>(a);
+  else if (c->variant == 4)
+    qk_sweep_flat_kernel<64, 8, false, 3><<<dim3(grid), dim3(WG_THREADS), lds_a, c->stream>>>(a);
+  else if (c->variant == 5)
+    qk_sweep_flat_kernel<64, 8, false, 4><<<dim3(grid), dim3(WG_THREADS), lds_a, c->stream>>>(a);
   else
     qk_sweep_flat_kernel<64, 8, false><<<dim3(grid), dim3(WG_THREADS), lds_a, c->stream>>>(a);
   HIP_TRY(hipGetLastError());
