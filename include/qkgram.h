@@ -146,6 +146,11 @@ int qk_overlaps_host(qk_ctx* ctx, const qk_mps_set* xset, const qk_mps_set* yset
 
 int qk_get_stats(qk_ctx* ctx, qk_stats* out);
 
+/* Diagnostic build only (QK_VARIANT=9): cycle sums of the instrumented sweep kernel's sections:
+ * out8 = {fetch issue, MFMA block, epilogue stores, stash (+vmcnt wait), barrier, phase prologue,
+ *         phase-end barrier, wave lifetime}.  Never used by the timed kernels. */
+int qk_debug_profile(qk_ctx* ctx, unsigned long long* out8);
+
 /* Device self-test of the f64 MFMA fragment maps the kernels rely on (returns
  * 0 if the 16x16x4 product of two known matrices matches the host result). */
 int qk_selftest_mfma(qk_ctx* ctx);

@@ -64,6 +64,7 @@ struct qk_ctx {
   double* scratch = nullptr;
   size_t scratch_bytes = 0;
   unsigned long long* counter = nullptr;
+  unsigned long long* prof = nullptr;  // 8 cycle sums of the diagnostic variant
   int variant = 1;     // sweep kernel variant (QK_VARIANT): 0 = v1 per-pass pipeline, 1 = flat 64x64/K8, 2 = flat 64x64/K16
   int wgs_per_cu = 2;  // resident workgroups per CU (QK_WGS_PER_CU)
   qk_stats last{};
@@ -268,6 +269,7 @@ struct SweepArgs {
   long long x_plane;  // doubles per X plane
   long long t_plane;  // doubles per T plane
   unsigned long long* counter;
+  unsigned long long* prof;  // diagnostic build only: cycle sums per section (see QK_VARIANT=9)
 };
 
 // C[M x N] = sum_k Aop[k][m] * Bop[k][n]   (complex, split planes; CONJB conjugates Bop)
@@ -462,6 +464,26 @@ __global__ __launch_bounds__(WG_THREADS, 2) void qk_sweep_kernel(const SweepArgs
 // K is walked in units of 4 (the MFMA k extent) up to the TRUE contraction length: rows beyond
 // it are zero padding and are skipped.
 // ----------------------------------------------------------------------------------------
+// In-kernel cycle stamp for the DIAGNOSTIC variant only (never in the timed kernels): s_memtime
+// with its own lgkmcnt(0), fenced against instruction motion.
+__device__ __forceinline__ long long qk_stamp() {
+  long long t;
+  __builtin_amdgcn_sched_barrier(0);
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+  __builtin_amdgcn_sched_barrier(0);
+  return t;
+}
+#define QK_T(slot_, ...)                   \
+  do {                                     \
+    if (PROF) {                            \
+      const long long t0_ = qk_stamp();    \
+      __VA_ARGS__;                         \
+      pc[slot_] += qk_stamp() - t0_;       \
+    } else {                               \
+      __VA_ARGS__;                         \
+    }                                      \
+  } while (0)
+
 template <int PN, int KTL>
 struct GemmCfg {
   static constexpr int PM = 64;
@@ -543,11 +565,11 @@ __device__ __forceinline__ void mma_ktile(v4d (&cre)[MAXT], v4d (&cim)[MAXT], co
   }
 }
 
-template <bool CONJB, int PN, int KTL, bool NTB>
+template <bool CONJB, int PN, int KTL, bool NTB, bool PROF>
 __device__ __forceinline__ void zgemm_flat(double* __restrict__ Cre, double* __restrict__ Cim, const int ldc,
                                            const double* __restrict__ Are, const double* __restrict__ Aim, const int lda,
                                            const double* __restrict__ Bre, const double* __restrict__ Bim, const int ldb,
-                                           const int M, const int N, const int Ktrue, double* __restrict__ lds) {
+                                           const int M, const int N, const int Ktrue, double* __restrict__ lds, long long (&pc)[8]) {
   using G = GemmCfg<PN, KTL>;
   constexpr int PM = G::PM;
   const int tid = threadIdx.x;
@@ -626,11 +648,9 @@ __device__ __forceinline__ void zgemm_flat(double* __restrict__ Cre, double* __r
   int cnt = 0;                       // valid output tiles of this wave in the current pass
   int c_kt = 0, c_pm = 0, c_pn = 0;  // position of the step being COMPUTED
 
-  fetch();
-  stash(0);
-  __syncthreads();
+  QK_T(5, { fetch(); stash(0); __syncthreads(); });
   for (int s = 0; s < total; ++s) {
-    if (s + 1 < total) fetch();
+    QK_T(0, { if (s + 1 < total) fetch(); });
     const int m0 = c_pm * PM, n0 = c_pn * PN;
     if (c_kt == 0) {
       const int mt = min(PM / TILE, (M - m0) / TILE);
@@ -648,10 +668,13 @@ __device__ __forceinline__ void zgemm_flat(double* __restrict__ Cre, double* __r
     }
     const double* base = lds + (s & 1) * G::STAGE_D;
     const int ksteps = min(KTL / 4, k4 - c_kt * (KTL / 4));
-    if (ksteps == KTL / 4)
-      mma_ktile<CONJB, PM, PN, G::A_PLANE, G::B_PLANE, KTL / 4, G::MAXT, true>(cre, cim, tm, tn, base, q, j, cnt, ksteps);
-    else
-      mma_ktile<CONJB, PM, PN, G::A_PLANE, G::B_PLANE, KTL / 4, G::MAXT, false>(cre, cim, tm, tn, base, q, j, cnt, ksteps);
+    QK_T(1, {
+      if (ksteps == KTL / 4)
+        mma_ktile<CONJB, PM, PN, G::A_PLANE, G::B_PLANE, KTL / 4, G::MAXT, true>(cre, cim, tm, tn, base, q, j, cnt, ksteps);
+      else
+        mma_ktile<CONJB, PM, PN, G::A_PLANE, G::B_PLANE, KTL / 4, G::MAXT, false>(cre, cim, tm, tn, base, q, j, cnt, ksteps);
+    });
+    const long long te_ = PROF ? qk_stamp() : 0;
     if (c_kt == nk - 1) {
 #pragma unroll
       for (int e = 0; e < G::MAXT; ++e) {
@@ -665,18 +688,19 @@ __device__ __forceinline__ void zgemm_flat(double* __restrict__ Cre, double* __r
         }
       }
     }
+    if (PROF) pc[2] += qk_stamp() - te_;
     if (++c_kt == nk) {
       c_kt = 0;
       if (++c_pm == npm) c_pm = 0, ++c_pn;
     }
-    if (s + 1 < total) stash((s + 1) & 1);
-    __syncthreads();
+    QK_T(3, { if (s + 1 < total) stash((s + 1) & 1); });
+    QK_T(4, { __syncthreads(); });
   }
   // make this phase's output visible to the whole workgroup before the next phase reads it
-  __syncthreads();
+  QK_T(6, { __syncthreads(); });
 }
 
-template <int PN, int KTL, bool NTB, int OCC = 2>
+template <int PN, int KTL, bool NTB, int OCC = 2, bool PROF = false>
 __global__ __launch_bounds__(WG_THREADS, OCC) void qk_sweep_flat_kernel(const SweepArgs g) {
   using G = GemmCfg<PN, KTL>;
   extern __shared__ __attribute__((aligned(16))) double lds[];
@@ -687,6 +711,8 @@ __global__ __launch_bounds__(WG_THREADS, OCC) void qk_sweep_flat_kernel(const Sw
   double* Tre = Xim + g.x_plane;
   double* Tim = Tre + g.t_plane;
   const int tid = threadIdx.x;
+  long long pc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  const long long t_begin = PROF ? qk_stamp() : 0;
 
   for (;;) {
     if (tid == 0) *slot = (long long)atomicAdd(g.counter, 1ull);
@@ -716,9 +742,9 @@ __global__ __launch_bounds__(WG_THREADS, OCC) void qk_sweep_flat_kernel(const Sw
       const double* Bre = g.ydata + yo[k];
       const double* Bim = Bre + (long long)b * 2 * b2;
       // phase 1: T[a x 2b2] = X^T B, contraction over the TRUE bond b_k of y
-      zgemm_flat<false, PN, KTL, NTB>(Tre, Tim, 2 * b2, Xre, Xim, a, Bre, Bim, 2 * b2, a, 2 * b2, yt[k], lds);
+      zgemm_flat<false, PN, KTL, NTB, PROF>(Tre, Tim, 2 * b2, Xre, Xim, a, Bre, Bim, 2 * b2, a, 2 * b2, yt[k], lds, pc);
       // phase 2: X'[b2 x a2] = T^T conj(A), contraction over the 2 * a_k true rows (L, p)
-      zgemm_flat<true, PN, KTL, NTB>(Xre, Xim, a2, Tre, Tim, b2, Are, Aim, a2, b2, a2, 2 * xt[k], lds);
+      zgemm_flat<true, PN, KTL, NTB, PROF>(Xre, Xim, a2, Tre, Tim, b2, Are, Aim, a2, b2, a2, 2 * xt[k], lds, pc);
     }
     if (tid == 0) {
       const double re = Xre[0], im = Xim[0];
@@ -729,6 +755,11 @@ __global__ __launch_bounds__(WG_THREADS, OCC) void qk_sweep_flat_kernel(const Sw
       }
     }
     __syncthreads();
+  }
+  if (PROF && g.prof && (tid & 63) == 0) {
+    pc[7] = qk_stamp() - t_begin;  // wave lifetime
+#pragma unroll
+    for (int c = 0; c < 8; ++c) atomicAdd(g.prof + c, (unsigned long long)pc[c]);
   }
 }
 
@@ -782,10 +813,13 @@ extern "C" int qk_ctx_create(int device_id, qk_ctx** out) {
   HIP_TRY(hipEventCreate(&c->ev0));
   HIP_TRY(hipEventCreate(&c->ev1));
   HIP_TRY(hipMalloc(&c->counter, sizeof(unsigned long long)));
+  HIP_TRY(hipMalloc(&c->prof, 8 * sizeof(unsigned long long)));
+  HIP_TRY(hipMemset(c->prof, 0, 8 * sizeof(unsigned long long)));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(qk_sweep_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(qk_sweep_flat_kernel<64, 8, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)GemmCfg<64, 8>::LDS_B));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(qk_sweep_flat_kernel<64, 16, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)GemmCfg<64, 16>::LDS_B));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(qk_sweep_flat_kernel<64, 16, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)GemmCfg<64, 16>::LDS_B));
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(qk_sweep_flat_kernel<64, 16, false, 2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)GemmCfg<64, 16>::LDS_B));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(qk_sweep_flat_kernel<64, 8, false, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)GemmCfg<64, 8>::LDS_B));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(qk_sweep_flat_kernel<64, 8, false, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)GemmCfg<64, 8>::LDS_B));
   if (const char* v = std::getenv("QK_VARIANT")) c->variant = std::atoi(v);
@@ -956,6 +990,7 @@ extern "C" int qk_gram_values(qk_ctx* c, const qk_mps_set* xs, const qk_mps_set*
   a.values = values_dev, a.z = z_dev;
   a.scratch = c->scratch, a.x_plane = x_plane, a.t_plane = t_plane;
   a.counter = c->counter;
+  a.prof = c->prof;
   HIP_TRY(hipMemsetAsync(c->counter, 0, sizeof(unsigned long long), c->stream));
   HIP_TRY(hipEventRecord(c->ev0, c->stream));
   constexpr size_t lds_a = GemmCfg<64, 8>::LDS_B, lds_b = GemmCfg<64, 16>::LDS_B;
@@ -965,7 +1000,10 @@ extern "C" int qk_gram_values(qk_ctx* c, const qk_mps_set* xs, const qk_mps_set*
     qk_sweep_flat_kernel<64, 16, false><<<dim3(grid), dim3(WG_THREADS), lds_b, c->stream>>>(a);
   else if (c->variant == 3)
     qk_sweep_flat_kernel<64, 16, true><<<dim3(grid), dim3(WG_THREADS), lds_b, c->stream>>>(a);
-  else if (c->variant == 4)
+  else if (c->variant == 9) {
+    HIP_TRY(hipMemsetAsync(c->prof, 0, 8 * sizeof(unsigned long long), c->stream));
+    qk_sweep_flat_kernel<64, 16, false, 2, true><<<dim3(grid), dim3(WG_THREADS), lds_b, c->stream>>>(a);
+  } else if (c->variant == 4)
     qk_sweep_flat_kernel<64, 8, false, 3><<<dim3(grid), dim3(WG_THREADS), lds_a, c->stream>>>(a);
   else if (c->variant == 5)
     qk_sweep_flat_kernel<64, 8, false, 4><<<dim3(grid), dim3(WG_THREADS), lds_a, c->stream>>>(a);
@@ -1086,6 +1124,14 @@ extern "C" int qk_overlaps_host(qk_ctx* c, const qk_mps_set* xs, const qk_mps_se
   (void)hipFree(d_z);
   qk_plan_destroy(plan);
   return rc;
+}
+
+extern "C" int qk_debug_profile(qk_ctx* c, unsigned long long* out8) {
+  if (!c || !out8) return fail(QK_EINVAL, "qk_debug_profile: null argument");
+  HIP_TRY(hipSetDevice(c->device));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  HIP_TRY(hipMemcpy(out8, c->prof, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+  return QK_OK;
 }
 
 extern "C" int qk_selftest_mfma(qk_ctx* c) {

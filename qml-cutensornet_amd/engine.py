@@ -68,6 +68,7 @@ _SIGNATURES = [
     ("qk_gram_host", C.c_int, [_P, _P, _P, _P, C.c_int64]),
     ("qk_overlaps_host", C.c_int, [_P, _P, _P, _P]),
     ("qk_get_stats", C.c_int, [_P, C.POINTER(QkStats)]),
+    ("qk_debug_profile", C.c_int, [_P, _P]),
     ("qk_selftest_mfma", C.c_int, [_P]),
 ]
 EXPORTED_SYMBOLS = [s[0] for s in _SIGNATURES]
@@ -259,6 +260,11 @@ class Context:
 
     def synchronize(self):
         _check(lib().qk_ctx_synchronize(self._h), "qk_ctx_synchronize")
+
+    def debug_profile(self):
+        out = (C.c_uint64 * 8)()
+        _check(lib().qk_debug_profile(self._h, out), "qk_debug_profile")
+        return list(out)
 
     def selftest(self):
         _check(lib().qk_selftest_mfma(self._h), "qk_selftest_mfma")
