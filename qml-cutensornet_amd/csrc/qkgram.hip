@@ -484,18 +484,19 @@ __device__ __forceinline__ long long qk_stamp() {
     }                                      \
   } while (0)
 
-template <int PN, int KTL>
+template <int PN, int KTL, int NW = 4>
 struct GemmCfg {
   static constexpr int PM = 64;
+  static constexpr int WGT = 64 * NW;  // threads per workgroup
   static constexpr int A_PLANE = KTL * PM;
   static constexpr int B_PLANE = KTL * PN;
   static constexpr int STAGE_D = 2 * A_PLANE + 2 * B_PLANE;  // doubles per buffer
   static constexpr int LDS_D = 2 * STAGE_D;
   static constexpr size_t LDS_B = (size_t)LDS_D * sizeof(double) + 16;
-  static constexpr int UA = (A_PLANE / 2) / WG_THREADS;  // 16-byte units per thread per A plane
-  static constexpr int UB = (B_PLANE / 2) / WG_THREADS;
-  static constexpr int MAXT = (PM / TILE) * (PN / TILE) / 4;  // output tiles per wave
-  static_assert(UA >= 1 && UB >= 1, "staging tile too small for 256 threads");
+  static constexpr int UA = (A_PLANE / 2) / WGT;  // 16-byte units per thread per A plane
+  static constexpr int UB = (B_PLANE / 2) / WGT;
+  static constexpr int MAXT = (PM / TILE) * (PN / TILE) / NW;  // output tiles per wave
+  static_assert(UA >= 1 && UB >= 1, "staging tile too small for the workgroup");
 };
 
 
@@ -503,10 +504,10 @@ struct GemmCfg {
 // Full K-tiles (the common case) run a software pipeline over "groups" of 2 k-steps: the LDS
 // fragment reads of group g+1 are issued before the 8 MFMAs of group g, so that the LDS latency
 // hides under 512 cycles of matrix work instead of stalling the wave at every group.
-template <bool CONJB, int PM, int PN, int A_PLANE, int B_PLANE, int KSTEPS, int MAXT, bool FULLK>
+template <bool CONJB, int PM, int PN, int A_PLANE, int B_PLANE, int KSTEPS, int MAXT, bool FULLK, bool PIPE = true>
 __device__ __forceinline__ void mma_ktile(v4d (&cre)[MAXT], v4d (&cim)[MAXT], const int (&tm)[MAXT], const int (&tn)[MAXT],
                                           const double* __restrict__ base, const int q, const int j, const int cnt, const int ksteps) {
-  if constexpr (FULLK && (KSTEPS % 2 == 0)) {
+  if constexpr (PIPE && FULLK && (KSTEPS % 2 == 0)) {
     constexpr int GPT = KSTEPS / 2;       // groups per tile
     constexpr int NG = MAXT * GPT;        // groups per K-tile
     double far[2][2], fai[2][2], fbr[2][2], fbi[2][2];  // [buffer][k-step in group]
@@ -565,12 +566,12 @@ __device__ __forceinline__ void mma_ktile(v4d (&cre)[MAXT], v4d (&cim)[MAXT], co
   }
 }
 
-template <bool CONJB, int PN, int KTL, bool NTB, bool PROF>
+template <bool CONJB, int PN, int KTL, bool NTB, bool PROF, bool PIPE = true, int NW = 4>
 __device__ __forceinline__ void zgemm_flat(double* __restrict__ Cre, double* __restrict__ Cim, const int ldc,
                                            const double* __restrict__ Are, const double* __restrict__ Aim, const int lda,
                                            const double* __restrict__ Bre, const double* __restrict__ Bim, const int ldb,
                                            const int M, const int N, const int Ktrue, double* __restrict__ lds, long long (&pc)[8]) {
-  using G = GemmCfg<PN, KTL>;
+  using G = GemmCfg<PN, KTL, NW>;
   constexpr int PM = G::PM;
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -597,7 +598,7 @@ __device__ __forceinline__ void zgemm_flat(double* __restrict__ Cre, double* __r
     const long long krow = (long long)f_kt * KTL;
 #pragma unroll
     for (int i = 0; i < G::UA; ++i) {
-      const int u = tid + WG_THREADS * i;
+      const int u = tid + G::WGT * i;
       const int row = u / (PM / 2), col = (u % (PM / 2)) * 2;
       if (col < mcols) {
         const long long o = (krow + row) * lda + m0 + col;
@@ -607,7 +608,7 @@ __device__ __forceinline__ void zgemm_flat(double* __restrict__ Cre, double* __r
     }
 #pragma unroll
     for (int i = 0; i < G::UB; ++i) {
-      const int u = tid + WG_THREADS * i;
+      const int u = tid + G::WGT * i;
       const int row = u / (PN / 2), col = (u % (PN / 2)) * 2;
       if (col < ncols) {
         const long long o = (krow + row) * ldb + n0 + col;
@@ -629,14 +630,14 @@ __device__ __forceinline__ void zgemm_flat(double* __restrict__ Cre, double* __r
     double* base = lds + buf * G::STAGE_D;
 #pragma unroll
     for (int i = 0; i < G::UA; ++i) {
-      const int u = tid + WG_THREADS * i;
+      const int u = tid + G::WGT * i;
       const int o = (u / (PM / 2)) * PM + (u % (PM / 2)) * 2;
       *reinterpret_cast<double2*>(base + o) = ra[2 * i];
       *reinterpret_cast<double2*>(base + G::A_PLANE + o) = ra[2 * i + 1];
     }
 #pragma unroll
     for (int i = 0; i < G::UB; ++i) {
-      const int u = tid + WG_THREADS * i;
+      const int u = tid + G::WGT * i;
       const int o = (u / (PN / 2)) * PN + (u % (PN / 2)) * 2;
       *reinterpret_cast<double2*>(base + 2 * G::A_PLANE + o) = rb[2 * i];
       *reinterpret_cast<double2*>(base + 2 * G::A_PLANE + G::B_PLANE + o) = rb[2 * i + 1];
@@ -656,12 +657,12 @@ __device__ __forceinline__ void zgemm_flat(double* __restrict__ Cre, double* __r
       const int mt = min(PM / TILE, (M - m0) / TILE);
       const int nt = min(PN / TILE, (N - n0) / TILE);
       const int vt = mt * nt;
-      cnt = (vt > wave) ? (vt - wave + 3) >> 2 : 0;  // tiles t = wave + 4e < vt
+      cnt = (vt > wave) ? (vt - wave + NW - 1) / NW : 0;  // tiles t = wave + NW e < vt
 #pragma unroll
       for (int e = 0; e < G::MAXT; ++e) {
         cre[e] = (v4d){0, 0, 0, 0};
         cim[e] = (v4d){0, 0, 0, 0};
-        const int t = min(wave + 4 * e, vt - 1);  // clamp: entries e >= cnt are never used
+        const int t = min(wave + NW * e, vt - 1);  // clamp: entries e >= cnt are never used
         tm[e] = t % mt;
         tn[e] = t / mt;
       }
@@ -670,7 +671,7 @@ __device__ __forceinline__ void zgemm_flat(double* __restrict__ Cre, double* __r
     const int ksteps = min(KTL / 4, k4 - c_kt * (KTL / 4));
     QK_T(1, {
       if (ksteps == KTL / 4)
-        mma_ktile<CONJB, PM, PN, G::A_PLANE, G::B_PLANE, KTL / 4, G::MAXT, true>(cre, cim, tm, tn, base, q, j, cnt, ksteps);
+        mma_ktile<CONJB, PM, PN, G::A_PLANE, G::B_PLANE, KTL / 4, G::MAXT, true, PIPE>(cre, cim, tm, tn, base, q, j, cnt, ksteps);
       else
         mma_ktile<CONJB, PM, PN, G::A_PLANE, G::B_PLANE, KTL / 4, G::MAXT, false>(cre, cim, tm, tn, base, q, j, cnt, ksteps);
     });
@@ -700,9 +701,9 @@ __device__ __forceinline__ void zgemm_flat(double* __restrict__ Cre, double* __r
   QK_T(6, { __syncthreads(); });
 }
 
-template <int PN, int KTL, bool NTB, int OCC = 2, bool PROF = false>
-__global__ __launch_bounds__(WG_THREADS, OCC) void qk_sweep_flat_kernel(const SweepArgs g) {
-  using G = GemmCfg<PN, KTL>;
+template <int PN, int KTL, bool NTB, int OCC = 2, bool PROF = false, int NW = 4>
+__global__ __launch_bounds__(64 * NW, OCC) void qk_sweep_flat_kernel(const SweepArgs g) {
+  using G = GemmCfg<PN, KTL, NW>;
   extern __shared__ __attribute__((aligned(16))) double lds[];
   long long* slot = reinterpret_cast<long long*>(lds + G::LDS_D);
 
@@ -729,7 +730,7 @@ __global__ __launch_bounds__(WG_THREADS, OCC) void qk_sweep_flat_kernel(const Sw
     const int64_t* yo = g.yoffs + (long long)yj * g.n_sites;
     {
       const int a = xd[0], b = yd[0];
-      for (int e = tid; e < a * b; e += WG_THREADS) {
+      for (int e = tid; e < a * b; e += 64 * NW) {
         Xre[e] = (e == 0) ? 1.0 : 0.0;
         Xim[e] = 0.0;
       }
@@ -742,9 +743,9 @@ __global__ __launch_bounds__(WG_THREADS, OCC) void qk_sweep_flat_kernel(const Sw
       const double* Bre = g.ydata + yo[k];
       const double* Bim = Bre + (long long)b * 2 * b2;
       // phase 1: T[a x 2b2] = X^T B, contraction over the TRUE bond b_k of y
-      zgemm_flat<false, PN, KTL, NTB, PROF>(Tre, Tim, 2 * b2, Xre, Xim, a, Bre, Bim, 2 * b2, a, 2 * b2, yt[k], lds, pc);
+      zgemm_flat<false, PN, KTL, NTB, PROF, (OCC < 3 || NW > 4), NW>(Tre, Tim, 2 * b2, Xre, Xim, a, Bre, Bim, 2 * b2, a, 2 * b2, yt[k], lds, pc);
       // phase 2: X'[b2 x a2] = T^T conj(A), contraction over the 2 * a_k true rows (L, p)
-      zgemm_flat<true, PN, KTL, NTB, PROF>(Xre, Xim, a2, Tre, Tim, b2, Are, Aim, a2, b2, a2, 2 * xt[k], lds, pc);
+      zgemm_flat<true, PN, KTL, NTB, PROF, (OCC < 3 || NW > 4), NW>(Xre, Xim, a2, Tre, Tim, b2, Are, Aim, a2, b2, a2, 2 * xt[k], lds, pc);
     }
     if (tid == 0) {
       const double re = Xre[0], im = Xim[0];
@@ -820,6 +821,7 @@ extern "C" int qk_ctx_create(int device_id, qk_ctx** out) {
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(qk_sweep_flat_kernel<64, 16, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)GemmCfg<64, 16>::LDS_B));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(qk_sweep_flat_kernel<64, 16, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)GemmCfg<64, 16>::LDS_B));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(qk_sweep_flat_kernel<64, 16, false, 2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)GemmCfg<64, 16>::LDS_B));
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(qk_sweep_flat_kernel<64, 16, false, 4, false, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)GemmCfg<64, 16, 8>::LDS_B));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(qk_sweep_flat_kernel<64, 8, false, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)GemmCfg<64, 8>::LDS_B));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(qk_sweep_flat_kernel<64, 8, false, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)GemmCfg<64, 8>::LDS_B));
   if (const char* v = std::getenv("QK_VARIANT")) c->variant = std::atoi(v);
@@ -1000,6 +1002,8 @@ extern "C" int qk_gram_values(qk_ctx* c, const qk_mps_set* xs, const qk_mps_set*
     qk_sweep_flat_kernel<64, 16, false><<<dim3(grid), dim3(WG_THREADS), lds_b, c->stream>>>(a);
   else if (c->variant == 3)
     qk_sweep_flat_kernel<64, 16, true><<<dim3(grid), dim3(WG_THREADS), lds_b, c->stream>>>(a);
+  else if (c->variant == 6)
+    qk_sweep_flat_kernel<64, 16, false, 4, false, 8><<<dim3(grid), dim3(512), lds_b, c->stream>>>(a);
   else if (c->variant == 9) {
     HIP_TRY(hipMemsetAsync(c->prof, 0, 8 * sizeof(unsigned long long), c->stream));
     qk_sweep_flat_kernel<64, 16, false, 2, true><<<dim3(grid), dim3(WG_THREADS), lds_b, c->stream>>>(a);
