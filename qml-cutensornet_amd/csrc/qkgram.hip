@@ -484,9 +484,9 @@ __device__ __forceinline__ long long qk_stamp() {
     }                                      \
   } while (0)
 
-template <int PN, int KTL, int NW = 4>
+template <int PN, int KTL, int NW = 4, int PM_ = 64>
 struct GemmCfg {
-  static constexpr int PM = 64;
+  static constexpr int PM = PM_;
   static constexpr int WGT = 64 * NW;  // threads per workgroup
   static constexpr int A_PLANE = KTL * PM;
   static constexpr int B_PLANE = KTL * PN;
@@ -566,12 +566,12 @@ __device__ __forceinline__ void mma_ktile(v4d (&cre)[MAXT], v4d (&cim)[MAXT], co
   }
 }
 
-template <bool CONJB, int PN, int KTL, bool NTB, bool PROF, bool PIPE = true, int NW = 4>
+template <bool CONJB, int PN, int KTL, bool NTB, bool PROF, bool PIPE = true, int NW = 4, int PMT = 64>
 __device__ __forceinline__ void zgemm_flat(double* __restrict__ Cre, double* __restrict__ Cim, const int ldc,
                                            const double* __restrict__ Are, const double* __restrict__ Aim, const int lda,
                                            const double* __restrict__ Bre, const double* __restrict__ Bim, const int ldb,
                                            const int M, const int N, const int Ktrue, double* __restrict__ lds, long long (&pc)[8]) {
-  using G = GemmCfg<PN, KTL, NW>;
+  using G = GemmCfg<PN, KTL, NW, PMT>;
   constexpr int PM = G::PM;
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -701,9 +701,9 @@ __device__ __forceinline__ void zgemm_flat(double* __restrict__ Cre, double* __r
   QK_T(6, { __syncthreads(); });
 }
 
-template <int PN, int KTL, bool NTB, int OCC = 2, bool PROF = false, int NW = 4>
+template <int PN, int KTL, bool NTB, int OCC = 2, bool PROF = false, int NW = 4, int PMT = 64>
 __global__ __launch_bounds__(64 * NW, OCC) void qk_sweep_flat_kernel(const SweepArgs g) {
-  using G = GemmCfg<PN, KTL, NW>;
+  using G = GemmCfg<PN, KTL, NW, PMT>;
   extern __shared__ __attribute__((aligned(16))) double lds[];
   long long* slot = reinterpret_cast<long long*>(lds + G::LDS_D);
 
@@ -743,9 +743,9 @@ __global__ __launch_bounds__(64 * NW, OCC) void qk_sweep_flat_kernel(const Sweep
       const double* Bre = g.ydata + yo[k];
       const double* Bim = Bre + (long long)b * 2 * b2;
       // phase 1: T[a x 2b2] = X^T B, contraction over the TRUE bond b_k of y
-      zgemm_flat<false, PN, KTL, NTB, PROF, (OCC < 3 || NW > 4), NW>(Tre, Tim, 2 * b2, Xre, Xim, a, Bre, Bim, 2 * b2, a, 2 * b2, yt[k], lds, pc);
+      zgemm_flat<false, PN, KTL, NTB, PROF, (PMT == 64 && (OCC < 3 || NW > 4)), NW, PMT>(Tre, Tim, 2 * b2, Xre, Xim, a, Bre, Bim, 2 * b2, a, 2 * b2, yt[k], lds, pc);
       // phase 2: X'[b2 x a2] = T^T conj(A), contraction over the 2 * a_k true rows (L, p)
-      zgemm_flat<true, PN, KTL, NTB, PROF, (OCC < 3 || NW > 4), NW>(Xre, Xim, a2, Tre, Tim, b2, Are, Aim, a2, b2, a2, 2 * xt[k], lds, pc);
+      zgemm_flat<true, PN, KTL, NTB, PROF, (PMT == 64 && (OCC < 3 || NW > 4)), NW, PMT>(Xre, Xim, a2, Tre, Tim, b2, Are, Aim, a2, b2, a2, 2 * xt[k], lds, pc);
     }
     if (tid == 0) {
       const double re = Xre[0], im = Xim[0];
@@ -822,6 +822,8 @@ extern "C" int qk_ctx_create(int device_id, qk_ctx** out) {
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(qk_sweep_flat_kernel<64, 16, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)GemmCfg<64, 16>::LDS_B));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(qk_sweep_flat_kernel<64, 16, false, 2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)GemmCfg<64, 16>::LDS_B));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(qk_sweep_flat_kernel<64, 16, false, 4, false, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)GemmCfg<64, 16, 8>::LDS_B));
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(qk_sweep_flat_kernel<32, 16, false, 3, false, 4, 64>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)GemmCfg<32, 16, 4, 64>::LDS_B));
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(qk_sweep_flat_kernel<128, 8, false, 2, false, 8, 128>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)GemmCfg<128, 8, 8, 128>::LDS_B));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(qk_sweep_flat_kernel<64, 8, false, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)GemmCfg<64, 8>::LDS_B));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(qk_sweep_flat_kernel<64, 8, false, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)GemmCfg<64, 8>::LDS_B));
   if (const char* v = std::getenv("QK_VARIANT")) c->variant = std::atoi(v);
@@ -1004,7 +1006,13 @@ extern "C" int qk_gram_values(qk_ctx* c, const qk_mps_set* xs, const qk_mps_set*
     qk_sweep_flat_kernel<64, 16, true><<<dim3(grid), dim3(WG_THREADS), lds_b, c->stream>>>(a);
   else if (c->variant == 6)
     qk_sweep_flat_kernel<64, 16, false, 4, false, 8><<<dim3(grid), dim3(512), lds_b, c->stream>>>(a);
-  else if (c->variant == 9) {
+  else if (c->variant == 8) {
+    constexpr size_t lds_d = GemmCfg<32, 16, 4, 64>::LDS_B;
+    qk_sweep_flat_kernel<32, 16, false, 3, false, 4, 64><<<dim3(grid), dim3(256), lds_d, c->stream>>>(a);
+  } else if (c->variant == 7) {
+    constexpr size_t lds_c = GemmCfg<128, 8, 8, 128>::LDS_B;
+    qk_sweep_flat_kernel<128, 8, false, 2, false, 8, 128><<<dim3(grid), dim3(512), lds_c, c->stream>>>(a);
+  } else if (c->variant == 9) {
     HIP_TRY(hipMemsetAsync(c->prof, 0, 8 * sizeof(unsigned long long), c->stream));
     qk_sweep_flat_kernel<64, 16, false, 2, true><<<dim3(grid), dim3(WG_THREADS), lds_b, c->stream>>>(a);
   } else if (c->variant == 4)
