@@ -370,8 +370,8 @@ __device__ __forceinline__ void zgemm_kmajor(double* __restrict__ Cre, double* _
               double bi = pb[PLANE + ks * 4 * PASS];
               if (CONJB) bi = -bi;
               cre[s] = __builtin_amdgcn_mfma_f64_16x16x4f64(ar, br, cre[s], 0, 0, 0);
-              cre[s] = __builtin_amdgcn_mfma_f64_16x16x4f64(-ai, bi, cre[s], 0, 0, 0);
               cim[s] = __builtin_amdgcn_mfma_f64_16x16x4f64(ar, bi, cim[s], 0, 0, 0);
+              cre[s] = __builtin_amdgcn_mfma_f64_16x16x4f64(-ai, bi, cre[s], 0, 0, 0);
               cim[s] = __builtin_amdgcn_mfma_f64_16x16x4f64(ai, br, cim[s], 0, 0, 0);
             }
           }
@@ -534,8 +534,8 @@ __device__ __forceinline__ void mma_ktile(v4d (&cre)[MAXT], v4d (&cim)[MAXT], co
         for (int h = 0; h < 2; ++h) {
           const double ar = far[g & 1][h], ai = fai[g & 1][h], br = fbr[g & 1][h], bi = fbi[g & 1][h];
           cre[e] = __builtin_amdgcn_mfma_f64_16x16x4f64(ar, br, cre[e], 0, 0, 0);
-          cre[e] = __builtin_amdgcn_mfma_f64_16x16x4f64(-ai, bi, cre[e], 0, 0, 0);
           cim[e] = __builtin_amdgcn_mfma_f64_16x16x4f64(ar, bi, cim[e], 0, 0, 0);
+          cre[e] = __builtin_amdgcn_mfma_f64_16x16x4f64(-ai, bi, cre[e], 0, 0, 0);
           cim[e] = __builtin_amdgcn_mfma_f64_16x16x4f64(ai, br, cim[e], 0, 0, 0);
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -556,8 +556,8 @@ __device__ __forceinline__ void mma_ktile(v4d (&cre)[MAXT], v4d (&cim)[MAXT], co
             double bi = pb[B_PLANE + ks * 4 * PN];
             if (CONJB) bi = -bi;
             cre[e] = __builtin_amdgcn_mfma_f64_16x16x4f64(ar, br, cre[e], 0, 0, 0);
-            cre[e] = __builtin_amdgcn_mfma_f64_16x16x4f64(-ai, bi, cre[e], 0, 0, 0);
             cim[e] = __builtin_amdgcn_mfma_f64_16x16x4f64(ar, bi, cim[e], 0, 0, 0);
+            cre[e] = __builtin_amdgcn_mfma_f64_16x16x4f64(-ai, bi, cre[e], 0, 0, 0);
             cim[e] = __builtin_amdgcn_mfma_f64_16x16x4f64(ai, br, cim[e], 0, 0, 0);
           }
         }
