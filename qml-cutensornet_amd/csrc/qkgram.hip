@@ -764,6 +764,37 @@ __global__ __launch_bounds__(64 * NW, OCC) void qk_sweep_flat_kernel(const Sweep
   }
 }
 
+// Diagnostic micro-kernel: the MFMA block alone (LDS fragments -> MFMAs), no global traffic and
+// no barriers inside the loop.  Measures how close mma_ktile gets to the matrix-pipe rate.
+template <int PN, int KTL, int NW, bool PIPE>
+__global__ __launch_bounds__(64 * NW, (NW == 8 ? 4 : 2)) void qk_mma_bench_kernel(int reps, double* out) {
+  using G = GemmCfg<PN, KTL, NW, 64>;
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int j = lane & 15, q = lane >> 4;
+  for (int e = tid; e < G::LDS_D; e += 64 * NW) lds[e] = 1e-3 * (double)((e * 7 + 3) % 11);
+  __syncthreads();
+  v4d cre[G::MAXT], cim[G::MAXT];
+  int tm[G::MAXT], tn[G::MAXT];
+#pragma unroll
+  for (int e = 0; e < G::MAXT; ++e) {
+    cre[e] = (v4d){0, 0, 0, 0};
+    cim[e] = (v4d){0, 0, 0, 0};
+    const int t = wave + NW * e;
+    tm[e] = t % 4;
+    tn[e] = t / 4;
+  }
+  for (int r = 0; r < reps; ++r)
+    mma_ktile<false, 64, PN, G::A_PLANE, G::B_PLANE, KTL / 4, G::MAXT, true, PIPE>(cre, cim, tm, tn, lds + (r & 1) * G::STAGE_D, q, j, G::MAXT, KTL / 4);
+  double acc = 0;
+#pragma unroll
+  for (int e = 0; e < G::MAXT; ++e)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc += cre[e][r] + cim[e][r];
+  out[(size_t)blockIdx.x * 64 * NW + tid] = acc;
+}
+
 __global__ void qk_scatter_kernel(const int32_t* __restrict__ pairs, const double* __restrict__ vals, long long n,
                                   double* __restrict__ K, long long ld, int mirror) {
   const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -822,6 +853,10 @@ extern "C" int qk_ctx_create(int device_id, qk_ctx** out) {
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(qk_sweep_flat_kernel<64, 16, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)GemmCfg<64, 16>::LDS_B));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(qk_sweep_flat_kernel<64, 16, false, 2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)GemmCfg<64, 16>::LDS_B));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(qk_sweep_flat_kernel<64, 16, false, 4, false, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)GemmCfg<64, 16, 8>::LDS_B));
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(qk_mma_bench_kernel<64, 16, 4, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)GemmCfg<64, 16, 4, 64>::LDS_B));
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(qk_mma_bench_kernel<64, 16, 4, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)GemmCfg<64, 16, 4, 64>::LDS_B));
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(qk_mma_bench_kernel<64, 16, 8, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)GemmCfg<64, 16, 4, 64>::LDS_B));
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(qk_mma_bench_kernel<64, 16, 8, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)GemmCfg<64, 16, 4, 64>::LDS_B));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(qk_sweep_flat_kernel<32, 16, false, 3, false, 4, 64>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)GemmCfg<32, 16, 4, 64>::LDS_B));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(qk_sweep_flat_kernel<128, 8, false, 2, false, 8, 128>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)GemmCfg<128, 8, 8, 128>::LDS_B));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(qk_sweep_flat_kernel<64, 8, false, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)GemmCfg<64, 8>::LDS_B));
@@ -1143,6 +1178,37 @@ extern "C" int qk_debug_profile(qk_ctx* c, unsigned long long* out8) {
   HIP_TRY(hipSetDevice(c->device));
   HIP_TRY(hipStreamSynchronize(c->stream));
   HIP_TRY(hipMemcpy(out8, c->prof, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+  return QK_OK;
+}
+
+// Diagnostic: TFLOP/s of the bare MFMA block. which: 0 = 4 waves PIPE, 1 = 4 waves no PIPE, 2 = 8 waves PIPE, 3 = 8 waves no PIPE
+extern "C" int qk_debug_mma_bench(qk_ctx* c, int which, int wgs_per_cu, int reps, double* tflops) {
+  if (!c || !tflops) return fail(QK_EINVAL, "qk_debug_mma_bench: null argument");
+  HIP_TRY(hipSetDevice(c->device));
+  const int nw = (which >= 2) ? 8 : 4;
+  const int grid = c->num_cus * wgs_per_cu;
+  double* out = nullptr;
+  HIP_TRY(hipMalloc(&out, (size_t)grid * 64 * nw * sizeof(double)));
+  const size_t lds = GemmCfg<64, 16, 4, 64>::LDS_B;
+  hipEvent_t e0, e1;
+  HIP_TRY(hipEventCreate(&e0));
+  HIP_TRY(hipEventCreate(&e1));
+  for (int it = 0; it < 2; ++it) {
+    HIP_TRY(hipEventRecord(e0, c->stream));
+    if (which == 0) qk_mma_bench_kernel<64, 16, 4, true><<<dim3(grid), dim3(256), lds, c->stream>>>(reps, out);
+    else if (which == 1) qk_mma_bench_kernel<64, 16, 4, false><<<dim3(grid), dim3(256), lds, c->stream>>>(reps, out);
+    else if (which == 2) qk_mma_bench_kernel<64, 16, 8, true><<<dim3(grid), dim3(512), lds, c->stream>>>(reps, out);
+    else qk_mma_bench_kernel<64, 16, 8, false><<<dim3(grid), dim3(512), lds, c->stream>>>(reps, out);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(e1, c->stream));
+    HIP_TRY(hipEventSynchronize(e1));
+  }
+  float ms = 0;
+  HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+  // per WG per rep: 16 tiles x 4 k-steps x 4 MFMAs x 2048 flop
+  *tflops = (double)grid * reps * 16.0 * 4 * 4 * 2048 / (ms * 1e-3) / 1e12;
+  (void)hipFree(out);
+  (void)hipEventDestroy(e0), (void)hipEventDestroy(e1);
   return QK_OK;
 }
 

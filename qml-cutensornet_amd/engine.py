@@ -69,6 +69,7 @@ _SIGNATURES = [
     ("qk_overlaps_host", C.c_int, [_P, _P, _P, _P]),
     ("qk_get_stats", C.c_int, [_P, C.POINTER(QkStats)]),
     ("qk_debug_profile", C.c_int, [_P, _P]),
+    ("qk_debug_mma_bench", C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double)]),
     ("qk_selftest_mfma", C.c_int, [_P]),
 ]
 EXPORTED_SYMBOLS = [s[0] for s in _SIGNATURES]
@@ -260,6 +261,11 @@ class Context:
 
     def synchronize(self):
         _check(lib().qk_ctx_synchronize(self._h), "qk_ctx_synchronize")
+
+    def debug_mma_bench(self, which, wgs_per_cu, reps=2000):
+        out = C.c_double()
+        _check(lib().qk_debug_mma_bench(self._h, which, wgs_per_cu, reps, C.byref(out)), "qk_debug_mma_bench")
+        return out.value
 
     def debug_profile(self):
         out = (C.c_uint64 * 8)()
