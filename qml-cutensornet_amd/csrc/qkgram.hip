@@ -566,7 +566,7 @@ __device__ __forceinline__ void mma_ktile(v4d (&cre)[MAXT], v4d (&cim)[MAXT], co
   }
 }
 
-template <bool CONJB, int PN, int KTL, bool NTB, bool PROF, bool PIPE = true, int NW = 4, int PMT = 64>
+template <bool CONJB, int PN, int KTL, bool NTB, bool PROF, bool PIPE = true, int NW = 4, int PMT = 64, bool GLDS = false>
 __device__ __forceinline__ void zgemm_flat(double* __restrict__ Cre, double* __restrict__ Cim, const int ldc,
                                            const double* __restrict__ Are, const double* __restrict__ Aim, const int lda,
                                            const double* __restrict__ Bre, const double* __restrict__ Bim, const int ldb,
@@ -592,8 +592,11 @@ __device__ __forceinline__ void zgemm_flat(double* __restrict__ Cre, double* __r
 
   // position of the step being FETCHED
   int f_kt = 0, f_pm = 0, f_pn = 0;
-  auto fetch = [&]() __attribute__((always_inline)) {
+  typedef __attribute__((address_space(3))) void* lds_ptr_t;
+  auto fetch = [&](int buf) __attribute__((always_inline)) {
     const int m0 = f_pm * PM, n0 = f_pn * PN;
+    double* stage = lds + buf * G::STAGE_D;
+    const int u_wave = tid - lane;  // first staging unit of this wave (wave-uniform)
     const int mcols = min(PM, M - m0), ncols = min(PN, N - n0);
     const long long krow = (long long)f_kt * KTL;
 #pragma unroll
@@ -602,8 +605,14 @@ __device__ __forceinline__ void zgemm_flat(double* __restrict__ Cre, double* __r
       const int row = u / (PM / 2), col = (u % (PM / 2)) * 2;
       if (col < mcols) {
         const long long o = (krow + row) * lda + m0 + col;
-        ra[2 * i] = *reinterpret_cast<const double2*>(Are + o);
-        ra[2 * i + 1] = *reinterpret_cast<const double2*>(Aim + o);
+        if (GLDS) {  // direct-to-LDS DMA: lane l of the wave lands at (wave base) + 16 l bytes = element 2u of the plane
+          double* d = stage + 2 * (u_wave + G::WGT * i);
+          __builtin_amdgcn_global_load_lds(Are + o, (lds_ptr_t)d, 16, 0, 0);
+          __builtin_amdgcn_global_load_lds(Aim + o, (lds_ptr_t)(d + G::A_PLANE), 16, 0, 0);
+        } else {
+          ra[2 * i] = *reinterpret_cast<const double2*>(Are + o);
+          ra[2 * i + 1] = *reinterpret_cast<const double2*>(Aim + o);
+        }
       }
     }
 #pragma unroll
@@ -612,7 +621,11 @@ __device__ __forceinline__ void zgemm_flat(double* __restrict__ Cre, double* __r
       const int row = u / (PN / 2), col = (u % (PN / 2)) * 2;
       if (col < ncols) {
         const long long o = (krow + row) * ldb + n0 + col;
-        if (NTB) {
+        if (GLDS) {
+          double* d = stage + 2 * G::A_PLANE + 2 * (u_wave + G::WGT * i);
+          __builtin_amdgcn_global_load_lds(Bre + o, (lds_ptr_t)d, 16, 0, 0);
+          __builtin_amdgcn_global_load_lds(Bim + o, (lds_ptr_t)(d + G::B_PLANE), 16, 0, 0);
+        } else if (NTB) {
           rb[2 * i] = load_stream(Bre + o);
           rb[2 * i + 1] = load_stream(Bim + o);
         } else {
@@ -627,6 +640,7 @@ __device__ __forceinline__ void zgemm_flat(double* __restrict__ Cre, double* __r
     }
   };
   auto stash = [&](int buf) __attribute__((always_inline)) {
+    if (GLDS) return;  // the DMA already wrote the buffer
     double* base = lds + buf * G::STAGE_D;
 #pragma unroll
     for (int i = 0; i < G::UA; ++i) {
@@ -649,9 +663,9 @@ __device__ __forceinline__ void zgemm_flat(double* __restrict__ Cre, double* __r
   int cnt = 0;                       // valid output tiles of this wave in the current pass
   int c_kt = 0, c_pm = 0, c_pn = 0;  // position of the step being COMPUTED
 
-  QK_T(5, { fetch(); stash(0); __syncthreads(); });
+  QK_T(5, { fetch(0); stash(0); __syncthreads(); });
   for (int s = 0; s < total; ++s) {
-    QK_T(0, { if (s + 1 < total) fetch(); });
+    QK_T(0, { if (s + 1 < total) fetch((s + 1) & 1); });
     const int m0 = c_pm * PM, n0 = c_pn * PN;
     if (c_kt == 0) {
       const int mt = min(PM / TILE, (M - m0) / TILE);
@@ -701,7 +715,7 @@ __device__ __forceinline__ void zgemm_flat(double* __restrict__ Cre, double* __r
   QK_T(6, { __syncthreads(); });
 }
 
-template <int PN, int KTL, bool NTB, int OCC = 2, bool PROF = false, int NW = 4, int PMT = 64>
+template <int PN, int KTL, bool NTB, int OCC = 2, bool PROF = false, int NW = 4, int PMT = 64, bool GLDS = false>
 __global__ __launch_bounds__(64 * NW, OCC) void qk_sweep_flat_kernel(const SweepArgs g) {
   using G = GemmCfg<PN, KTL, NW, PMT>;
   extern __shared__ __attribute__((aligned(16))) double lds[];
@@ -743,9 +757,9 @@ __global__ __launch_bounds__(64 * NW, OCC) void qk_sweep_flat_kernel(const Sweep
       const double* Bre = g.ydata + yo[k];
       const double* Bim = Bre + (long long)b * 2 * b2;
       // phase 1: T[a x 2b2] = X^T B, contraction over the TRUE bond b_k of y
-      zgemm_flat<false, PN, KTL, NTB, PROF, (PMT == 64 && (OCC < 3 || NW > 4)), NW, PMT>(Tre, Tim, 2 * b2, Xre, Xim, a, Bre, Bim, 2 * b2, a, 2 * b2, yt[k], lds, pc);
+      zgemm_flat<false, PN, KTL, NTB, PROF, (PMT == 64 && (OCC < 3 || NW > 4)), NW, PMT, GLDS>(Tre, Tim, 2 * b2, Xre, Xim, a, Bre, Bim, 2 * b2, a, 2 * b2, yt[k], lds, pc);
       // phase 2: X'[b2 x a2] = T^T conj(A), contraction over the 2 * a_k true rows (L, p)
-      zgemm_flat<true, PN, KTL, NTB, PROF, (PMT == 64 && (OCC < 3 || NW > 4)), NW, PMT>(Xre, Xim, a2, Tre, Tim, b2, Are, Aim, a2, b2, a2, 2 * xt[k], lds, pc);
+      zgemm_flat<true, PN, KTL, NTB, PROF, (PMT == 64 && (OCC < 3 || NW > 4)), NW, PMT, GLDS>(Xre, Xim, a2, Tre, Tim, b2, Are, Aim, a2, b2, a2, 2 * xt[k], lds, pc);
     }
     if (tid == 0) {
       const double re = Xre[0], im = Xim[0];
@@ -857,6 +871,8 @@ extern "C" int qk_ctx_create(int device_id, qk_ctx** out) {
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(qk_mma_bench_kernel<64, 16, 4, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)GemmCfg<64, 16, 4, 64>::LDS_B));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(qk_mma_bench_kernel<64, 16, 8, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)GemmCfg<64, 16, 4, 64>::LDS_B));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(qk_mma_bench_kernel<64, 16, 8, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)GemmCfg<64, 16, 4, 64>::LDS_B));
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(qk_sweep_flat_kernel<64, 16, false, 4, false, 8, 64, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)GemmCfg<64, 16, 8>::LDS_B));
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(qk_sweep_flat_kernel<64, 16, false, 2, false, 4, 64, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)GemmCfg<64, 16, 4>::LDS_B));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(qk_sweep_flat_kernel<32, 16, false, 3, false, 4, 64>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)GemmCfg<32, 16, 4, 64>::LDS_B));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(qk_sweep_flat_kernel<128, 8, false, 2, false, 8, 128>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)GemmCfg<128, 8, 8, 128>::LDS_B));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(qk_sweep_flat_kernel<64, 8, false, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)GemmCfg<64, 8>::LDS_B));
@@ -1041,6 +1057,10 @@ extern "C" int qk_gram_values(qk_ctx* c, const qk_mps_set* xs, const qk_mps_set*
     qk_sweep_flat_kernel<64, 16, true><<<dim3(grid), dim3(WG_THREADS), lds_b, c->stream>>>(a);
   else if (c->variant == 6)
     qk_sweep_flat_kernel<64, 16, false, 4, false, 8><<<dim3(grid), dim3(512), lds_b, c->stream>>>(a);
+  else if (c->variant == 10)
+    qk_sweep_flat_kernel<64, 16, false, 4, false, 8, 64, true><<<dim3(grid), dim3(512), lds_b, c->stream>>>(a);
+  else if (c->variant == 11)
+    qk_sweep_flat_kernel<64, 16, false, 2, false, 4, 64, true><<<dim3(grid), dim3(256), lds_b, c->stream>>>(a);
   else if (c->variant == 8) {
     constexpr size_t lds_d = GemmCfg<32, 16, 4, 64>::LDS_B;
     qk_sweep_flat_kernel<32, 16, false, 3, false, 4, 64><<<dim3(grid), dim3(256), lds_d, c->stream>>>(a);
