@@ -19,10 +19,14 @@ class GramJob:
     """Reusable plan + buffers for one (xset, yset) Gram on this rank's GPU."""
 
     def __init__(self, ctx: engine.Context, xset: engine.MpsSet, yset: engine.MpsSet | None = None,
-                 world_size: int = 1, rank: int = 0, group=None, block: int = 16):
+                 world_size: int = 1, rank: int = 0, group=None, block: int | None = None):
         self.ctx, self.xset, self.yset = ctx, xset, yset
         self.world, self.rank, self.group = int(world_size), int(rank), group
         self.symmetric = yset is None
+        if block is None:
+            import os
+
+            block = int(os.environ.get("QK_PLAN_BLOCK", "16"))
         self.nx = len(xset)
         self.ny = self.nx if self.symmetric else len(yset)
         ydims = None if self.symmetric else yset.dims
