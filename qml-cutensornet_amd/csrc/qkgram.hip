@@ -715,6 +715,212 @@ __device__ __forceinline__ void zgemm_flat(double* __restrict__ Cre, double* __r
   QK_T(6, { __syncthreads(); });
 }
 
+// ----------------------------------------------------------------------------------------
+// v3: the flat pipeline with a TWO-step-deep register prefetch.  Tile t is fetched from global
+// memory at the start of step t-2 and written to LDS at the end of step t-1, so every load has
+// two full MFMA blocks (~3-7 us) to land.  Two staging register sets alternate by tile parity;
+// the steady-state loop is unrolled by two with unconditional fetches so that the compiler's
+// vmcnt bookkeeping stays exact (a conditional fetch would force vmcnt(0) at the stash).
+// ----------------------------------------------------------------------------------------
+template <bool CONJB, int PN, int KTL, int NW, int PMT>
+__device__ __forceinline__ void zgemm_deep(double* __restrict__ Cre, double* __restrict__ Cim, const int ldc,
+                                           const double* __restrict__ Are, const double* __restrict__ Aim, const int lda,
+                                           const double* __restrict__ Bre, const double* __restrict__ Bim, const int ldb,
+                                           const int M, const int N, const int Ktrue, double* __restrict__ lds) {
+  using G = GemmCfg<PN, KTL, NW, PMT>;
+  constexpr int PM = G::PM;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int j = lane & 15, q = lane >> 4;
+  const int npm = (M + PM - 1) / PM;
+  const int npn = (N + PN - 1) / PN;
+  const int nk = (Ktrue + KTL - 1) / KTL;
+  const int k4 = (Ktrue + 3) >> 2;
+  const int total = npm * npn * nk;
+
+  double2 ra0[2 * G::UA], rb0[2 * G::UB], ra1[2 * G::UA], rb1[2 * G::UB];
+#pragma unroll
+  for (int i = 0; i < 2 * G::UA; ++i) ra0[i] = ra1[i] = make_double2(0.0, 0.0);
+#pragma unroll
+  for (int i = 0; i < 2 * G::UB; ++i) rb0[i] = rb1[i] = make_double2(0.0, 0.0);
+
+  int f_kt = 0, f_pm = 0, f_pn = 0;
+#define QK_FETCH_SET(RA, RB)                                                      \
+  do {                                                                            \
+    const int m0_ = f_pm * PM, n0_ = f_pn * PN;                                   \
+    const int mcols_ = min(PM, M - m0_), ncols_ = min(PN, N - n0_);               \
+    const long long krow_ = (long long)f_kt * KTL;                                \
+    _Pragma("unroll") for (int i = 0; i < G::UA; ++i) {                           \
+      const int u = tid + G::WGT * i;                                             \
+      const int row = u / (PM / 2), col = (u % (PM / 2)) * 2;                     \
+      if (col < mcols_) {                                                         \
+        const long long o = (krow_ + row) * lda + m0_ + col;                      \
+        RA[2 * i] = *reinterpret_cast<const double2*>(Are + o);                   \
+        RA[2 * i + 1] = *reinterpret_cast<const double2*>(Aim + o);               \
+      }                                                                           \
+    }                                                                             \
+    _Pragma("unroll") for (int i = 0; i < G::UB; ++i) {                           \
+      const int u = tid + G::WGT * i;                                             \
+      const int row = u / (PN / 2), col = (u % (PN / 2)) * 2;                     \
+      if (col < ncols_) {                                                         \
+        const long long o = (krow_ + row) * ldb + n0_ + col;                      \
+        RB[2 * i] = *reinterpret_cast<const double2*>(Bre + o);                   \
+        RB[2 * i + 1] = *reinterpret_cast<const double2*>(Bim + o);               \
+      }                                                                           \
+    }                                                                             \
+    if (++f_kt == nk) {                                                           \
+      f_kt = 0;                                                                   \
+      if (++f_pm == npm) f_pm = 0, ++f_pn;                                        \
+    }                                                                             \
+  } while (0)
+#define QK_STASH_SET(BUF, RA, RB)                                                 \
+  do {                                                                            \
+    double* base_ = lds + (BUF)*G::STAGE_D;                                       \
+    _Pragma("unroll") for (int i = 0; i < G::UA; ++i) {                           \
+      const int u = tid + G::WGT * i;                                             \
+      const int o = (u / (PM / 2)) * PM + (u % (PM / 2)) * 2;                     \
+      *reinterpret_cast<double2*>(base_ + o) = RA[2 * i];                         \
+      *reinterpret_cast<double2*>(base_ + G::A_PLANE + o) = RA[2 * i + 1];        \
+    }                                                                             \
+    _Pragma("unroll") for (int i = 0; i < G::UB; ++i) {                           \
+      const int u = tid + G::WGT * i;                                             \
+      const int o = (u / (PN / 2)) * PN + (u % (PN / 2)) * 2;                     \
+      *reinterpret_cast<double2*>(base_ + 2 * G::A_PLANE + o) = RB[2 * i];        \
+      *reinterpret_cast<double2*>(base_ + 2 * G::A_PLANE + G::B_PLANE + o) = RB[2 * i + 1]; \
+    }                                                                             \
+  } while (0)
+
+  v4d cre[G::MAXT], cim[G::MAXT];
+  int tm[G::MAXT], tn[G::MAXT];
+  int cnt = 0;
+  int c_kt = 0, c_pm = 0, c_pn = 0;
+  auto compute_step = [&](int buf) __attribute__((always_inline)) {
+    const int m0 = c_pm * PM, n0 = c_pn * PN;
+    if (c_kt == 0) {
+      const int mt = min(PM / TILE, (M - m0) / TILE);
+      const int nt = min(PN / TILE, (N - n0) / TILE);
+      const int vt = mt * nt;
+      cnt = (vt > wave) ? (vt - wave + NW - 1) / NW : 0;
+#pragma unroll
+      for (int e = 0; e < G::MAXT; ++e) {
+        cre[e] = (v4d){0, 0, 0, 0};
+        cim[e] = (v4d){0, 0, 0, 0};
+        const int t = min(wave + NW * e, vt - 1);
+        tm[e] = t % mt;
+        tn[e] = t / mt;
+      }
+    }
+    const double* base = lds + buf * G::STAGE_D;
+    const int ksteps = min(KTL / 4, k4 - c_kt * (KTL / 4));
+    if (ksteps == KTL / 4)
+      mma_ktile<CONJB, PM, PN, G::A_PLANE, G::B_PLANE, KTL / 4, G::MAXT, true, true>(cre, cim, tm, tn, base, q, j, cnt, ksteps);
+    else
+      mma_ktile<CONJB, PM, PN, G::A_PLANE, G::B_PLANE, KTL / 4, G::MAXT, false, true>(cre, cim, tm, tn, base, q, j, cnt, ksteps);
+    if (c_kt == nk - 1) {
+#pragma unroll
+      for (int e = 0; e < G::MAXT; ++e) {
+        if (e < cnt) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const long long o = (long long)(m0 + tm[e] * TILE + q + 4 * r) * ldc + n0 + tn[e] * TILE + j;
+            Cre[o] = cre[e][r];
+            Cim[o] = cim[e][r];
+          }
+        }
+      }
+    }
+    if (++c_kt == nk) {
+      c_kt = 0;
+      if (++c_pm == npm) c_pm = 0, ++c_pn;
+    }
+  };
+
+  // prologue: tiles 0 and 1 in flight, tile 0 published
+  QK_FETCH_SET(ra0, rb0);
+  if (total > 1) QK_FETCH_SET(ra1, rb1);
+  QK_STASH_SET(0, ra0, rb0);
+  __syncthreads();
+  int s = 0;
+  while (s + 3 < total) {  // tiles s+2 and s+3 exist: both fetches unconditional
+    QK_FETCH_SET(ra0, rb0);        // tile s+2
+    compute_step(0);               // tile s     (s is even here)
+    QK_STASH_SET(1, ra1, rb1);     // tile s+1, fetched two steps ago
+    __syncthreads();
+    QK_FETCH_SET(ra1, rb1);        // tile s+3
+    compute_step(1);               // tile s+1
+    QK_STASH_SET(0, ra0, rb0);     // tile s+2
+    __syncthreads();
+    s += 2;
+  }
+  for (; s < total; ++s) {  // tail (at most 3 steps); s keeps its parity convention
+    const bool even = (s & 1) == 0;
+    if (s + 2 < total) {
+      if (even) QK_FETCH_SET(ra0, rb0); else QK_FETCH_SET(ra1, rb1);
+    }
+    compute_step(s & 1);
+    if (s + 1 < total) {
+      if (even) QK_STASH_SET(1, ra1, rb1); else QK_STASH_SET(0, ra0, rb0);
+    }
+    __syncthreads();
+  }
+#undef QK_FETCH_SET
+#undef QK_STASH_SET
+  __syncthreads();
+}
+
+template <int PN, int KTL, int OCC, int NW, int PMT>
+__global__ __launch_bounds__(64 * NW, OCC) void qk_sweep_deep_kernel(const SweepArgs g) {
+  using G = GemmCfg<PN, KTL, NW, PMT>;
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  long long* slot = reinterpret_cast<long long*>(lds + G::LDS_D);
+  double* Xre = g.scratch + (long long)blockIdx.x * 2 * (g.x_plane + g.t_plane);
+  double* Xim = Xre + g.x_plane;
+  double* Tre = Xim + g.x_plane;
+  double* Tim = Tre + g.t_plane;
+  const int tid = threadIdx.x;
+  for (;;) {
+    if (tid == 0) *slot = (long long)atomicAdd(g.counter, 1ull);
+    __syncthreads();
+    const long long p = *slot;
+    __syncthreads();
+    if (p >= g.npairs) break;
+    const int xi = g.pairs[2 * p], yj = g.pairs[2 * p + 1];
+    const int32_t* xd = g.xdims + (long long)xi * (g.n_sites + 1);
+    const int32_t* yd = g.ydims + (long long)yj * (g.n_sites + 1);
+    const int32_t* xt = g.xtrue + (long long)xi * (g.n_sites + 1);
+    const int32_t* yt = g.ytrue + (long long)yj * (g.n_sites + 1);
+    const int64_t* xo = g.xoffs + (long long)xi * g.n_sites;
+    const int64_t* yo = g.yoffs + (long long)yj * g.n_sites;
+    {
+      const int a = xd[0], b = yd[0];
+      for (int e = tid; e < a * b; e += 64 * NW) {
+        Xre[e] = (e == 0) ? 1.0 : 0.0;
+        Xim[e] = 0.0;
+      }
+      __syncthreads();
+    }
+    for (int k = 0; k < g.n_sites; ++k) {
+      const int a = xd[k], a2 = xd[k + 1], b = yd[k], b2 = yd[k + 1];
+      const double* Are = g.xdata + xo[k];
+      const double* Aim = Are + (long long)a * 2 * a2;
+      const double* Bre = g.ydata + yo[k];
+      const double* Bim = Bre + (long long)b * 2 * b2;
+      zgemm_deep<false, PN, KTL, NW, PMT>(Tre, Tim, 2 * b2, Xre, Xim, a, Bre, Bim, 2 * b2, a, 2 * b2, yt[k], lds);
+      zgemm_deep<true, PN, KTL, NW, PMT>(Xre, Xim, a2, Tre, Tim, b2, Are, Aim, a2, b2, a2, 2 * xt[k], lds);
+    }
+    if (tid == 0) {
+      const double re = Xre[0], im = Xim[0];
+      g.values[p] = re * re + im * im;
+      if (g.z) {
+        g.z[2 * p] = re;
+        g.z[2 * p + 1] = im;
+      }
+    }
+    __syncthreads();
+  }
+}
+
 template <int PN, int KTL, bool NTB, int OCC = 2, bool PROF = false, int NW = 4, int PMT = 64, bool GLDS = false>
 __global__ __launch_bounds__(64 * NW, OCC) void qk_sweep_flat_kernel(const SweepArgs g) {
   using G = GemmCfg<PN, KTL, NW, PMT>;
@@ -873,6 +1079,8 @@ extern "C" int qk_ctx_create(int device_id, qk_ctx** out) {
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(qk_mma_bench_kernel<64, 16, 8, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)GemmCfg<64, 16, 4, 64>::LDS_B));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(qk_sweep_flat_kernel<64, 16, false, 4, false, 8, 64, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)GemmCfg<64, 16, 8>::LDS_B));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(qk_sweep_flat_kernel<64, 16, false, 2, false, 4, 64, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)GemmCfg<64, 16, 4>::LDS_B));
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(qk_sweep_deep_kernel<64, 16, 2, 4, 64>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)GemmCfg<64, 16, 4>::LDS_B));
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(qk_sweep_deep_kernel<64, 16, 4, 8, 64>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)GemmCfg<64, 16, 8>::LDS_B));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(qk_sweep_flat_kernel<32, 16, false, 3, false, 4, 64>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)GemmCfg<32, 16, 4, 64>::LDS_B));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(qk_sweep_flat_kernel<128, 8, false, 2, false, 8, 128>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)GemmCfg<128, 8, 8, 128>::LDS_B));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(qk_sweep_flat_kernel<64, 8, false, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)GemmCfg<64, 8>::LDS_B));
@@ -1057,6 +1265,10 @@ extern "C" int qk_gram_values(qk_ctx* c, const qk_mps_set* xs, const qk_mps_set*
     qk_sweep_flat_kernel<64, 16, true><<<dim3(grid), dim3(WG_THREADS), lds_b, c->stream>>>(a);
   else if (c->variant == 6)
     qk_sweep_flat_kernel<64, 16, false, 4, false, 8><<<dim3(grid), dim3(512), lds_b, c->stream>>>(a);
+  else if (c->variant == 12)
+    qk_sweep_deep_kernel<64, 16, 2, 4, 64><<<dim3(grid), dim3(256), lds_b, c->stream>>>(a);
+  else if (c->variant == 13)
+    qk_sweep_deep_kernel<64, 16, 4, 8, 64><<<dim3(grid), dim3(512), lds_b, c->stream>>>(a);
   else if (c->variant == 10)
     qk_sweep_flat_kernel<64, 16, false, 4, false, 8, 64, true><<<dim3(grid), dim3(512), lds_b, c->stream>>>(a);
   else if (c->variant == 11)
