@@ -722,6 +722,10 @@ __device__ __forceinline__ void zgemm_flat(double* __restrict__ Cre, double* __r
 // the steady-state loop is unrolled by two with unconditional fetches so that the compiler's
 // vmcnt bookkeeping stays exact (a conditional fetch would force vmcnt(0) at the stash).
 // ----------------------------------------------------------------------------------------
+// Workgroup barrier that publishes LDS writes only: it does NOT drain outstanding global loads
+// (a __syncthreads() would wait vmcnt(0) and cancel the prefetch that is meant to stay in flight).
+__device__ __forceinline__ void qk_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 template <bool CONJB, int PN, int KTL, int NW, int PMT>
 __device__ __forceinline__ void zgemm_deep(double* __restrict__ Cre, double* __restrict__ Cim, const int ldc,
                                            const double* __restrict__ Are, const double* __restrict__ Aim, const int lda,
@@ -753,8 +757,8 @@ __device__ __forceinline__ void zgemm_deep(double* __restrict__ Cre, double* __r
     const long long krow_ = (long long)f_kt * KTL;                                \
     _Pragma("unroll") for (int i = 0; i < G::UA; ++i) {                           \
       const int u = tid + G::WGT * i;                                             \
-      const int row = u / (PM / 2), col = (u % (PM / 2)) * 2;                     \
-      if (col < mcols_) {                                                         \
+      const int row = u / (PM / 2), col = min((u % (PM / 2)) * 2, mcols_ - 2);    \
+      {                                                                           \
         const long long o = (krow_ + row) * lda + m0_ + col;                      \
         RA[2 * i] = *reinterpret_cast<const double2*>(Are + o);                   \
         RA[2 * i + 1] = *reinterpret_cast<const double2*>(Aim + o);               \
@@ -762,8 +766,8 @@ __device__ __forceinline__ void zgemm_deep(double* __restrict__ Cre, double* __r
     }                                                                             \
     _Pragma("unroll") for (int i = 0; i < G::UB; ++i) {                           \
       const int u = tid + G::WGT * i;                                             \
-      const int row = u / (PN / 2), col = (u % (PN / 2)) * 2;                     \
-      if (col < ncols_) {                                                         \
+      const int row = u / (PN / 2), col = min((u % (PN / 2)) * 2, ncols_ - 2);    \
+      {                                                                           \
         const long long o = (krow_ + row) * ldb + n0_ + col;                      \
         RB[2 * i] = *reinterpret_cast<const double2*>(Bre + o);                   \
         RB[2 * i + 1] = *reinterpret_cast<const double2*>(Bim + o);               \
@@ -840,17 +844,17 @@ __device__ __forceinline__ void zgemm_deep(double* __restrict__ Cre, double* __r
   QK_FETCH_SET(ra0, rb0);
   if (total > 1) QK_FETCH_SET(ra1, rb1);
   QK_STASH_SET(0, ra0, rb0);
-  __syncthreads();
+  qk_lds_barrier();
   int s = 0;
   while (s + 3 < total) {  // tiles s+2 and s+3 exist: both fetches unconditional
     QK_FETCH_SET(ra0, rb0);        // tile s+2
     compute_step(0);               // tile s     (s is even here)
     QK_STASH_SET(1, ra1, rb1);     // tile s+1, fetched two steps ago
-    __syncthreads();
+    qk_lds_barrier();
     QK_FETCH_SET(ra1, rb1);        // tile s+3
     compute_step(1);               // tile s+1
     QK_STASH_SET(0, ra0, rb0);     // tile s+2
-    __syncthreads();
+    qk_lds_barrier();
     s += 2;
   }
   for (; s < total; ++s) {  // tail (at most 3 steps); s keeps its parity convention
@@ -862,7 +866,7 @@ __device__ __forceinline__ void zgemm_deep(double* __restrict__ Cre, double* __r
     if (s + 1 < total) {
       if (even) QK_STASH_SET(1, ra1, rb1); else QK_STASH_SET(0, ra0, rb0);
     }
-    __syncthreads();
+    qk_lds_barrier();
   }
 #undef QK_FETCH_SET
 #undef QK_STASH_SET
