@@ -65,7 +65,7 @@ struct qk_ctx {
   size_t scratch_bytes = 0;
   unsigned long long* counter = nullptr;
   unsigned long long* prof = nullptr;  // 8 cycle sums of the diagnostic variant
-  int variant = 1;     // sweep kernel variant (QK_VARIANT): 0 = v1 per-pass pipeline, 1 = flat 64x64/K8, 2 = flat 64x64/K16
+  int variant = 13;    // sweep kernel variant (QK_VARIANT): 13 = shipped (deep prefetch, 8 waves); 0, 2, 12 = earlier kernels kept for A/B; 9 = instrumented
   int wgs_per_cu = 2;  // resident workgroups per CU (QK_WGS_PER_CU)
   qk_stats last{};
 };
@@ -231,15 +231,6 @@ extern "C" int qk_plan_stats(const qk_plan* p, qk_stats* out) {
 // device code
 // ----------------------------------------------------------------------------------------
 typedef double v4d __attribute__((ext_vector_type(4)));
-typedef double v2d __attribute__((ext_vector_type(2)));
-
-// 16-byte load of a streamed (read-once) operand: non-temporal so that it does not push the
-// workgroup's X/T scratch lines out of the XCD's L2
-__device__ __forceinline__ double2 load_stream(const double* p) {
-  const v2d v = __builtin_nontemporal_load(reinterpret_cast<const v2d*>(p));
-  return make_double2(v.x, v.y);
-}
-
 // Staging geometry of the complex GEMM: a workgroup (4 waves) produces one 64x64 complex
 // output block per pass; operands are staged k-major through LDS in K-tiles of 16 rows,
 // 4 planes (A re/im, B re/im) of [16][64] doubles, double-buffered = 64 KiB.
@@ -566,7 +557,7 @@ __device__ __forceinline__ void mma_ktile(v4d (&cre)[MAXT], v4d (&cim)[MAXT], co
   }
 }
 
-template <bool CONJB, int PN, int KTL, bool NTB, bool PROF, bool PIPE = true, int NW = 4, int PMT = 64, bool GLDS = false>
+template <bool CONJB, int PN, int KTL, bool PROF, int NW = 4, int PMT = 64>
 __device__ __forceinline__ void zgemm_flat(double* __restrict__ Cre, double* __restrict__ Cim, const int ldc,
                                            const double* __restrict__ Are, const double* __restrict__ Aim, const int lda,
                                            const double* __restrict__ Bre, const double* __restrict__ Bim, const int ldb,
@@ -592,11 +583,8 @@ __device__ __forceinline__ void zgemm_flat(double* __restrict__ Cre, double* __r
 
   // position of the step being FETCHED
   int f_kt = 0, f_pm = 0, f_pn = 0;
-  typedef __attribute__((address_space(3))) void* lds_ptr_t;
-  auto fetch = [&](int buf) __attribute__((always_inline)) {
+  auto fetch = [&]() __attribute__((always_inline)) {
     const int m0 = f_pm * PM, n0 = f_pn * PN;
-    double* stage = lds + buf * G::STAGE_D;
-    const int u_wave = tid - lane;  // first staging unit of this wave (wave-uniform)
     const int mcols = min(PM, M - m0), ncols = min(PN, N - n0);
     const long long krow = (long long)f_kt * KTL;
 #pragma unroll
@@ -605,14 +593,8 @@ __device__ __forceinline__ void zgemm_flat(double* __restrict__ Cre, double* __r
       const int row = u / (PM / 2), col = (u % (PM / 2)) * 2;
       if (col < mcols) {
         const long long o = (krow + row) * lda + m0 + col;
-        if (GLDS) {  // direct-to-LDS DMA: lane l of the wave lands at (wave base) + 16 l bytes = element 2u of the plane
-          double* d = stage + 2 * (u_wave + G::WGT * i);
-          __builtin_amdgcn_global_load_lds(Are + o, (lds_ptr_t)d, 16, 0, 0);
-          __builtin_amdgcn_global_load_lds(Aim + o, (lds_ptr_t)(d + G::A_PLANE), 16, 0, 0);
-        } else {
-          ra[2 * i] = *reinterpret_cast<const double2*>(Are + o);
-          ra[2 * i + 1] = *reinterpret_cast<const double2*>(Aim + o);
-        }
+        ra[2 * i] = *reinterpret_cast<const double2*>(Are + o);
+        ra[2 * i + 1] = *reinterpret_cast<const double2*>(Aim + o);
       }
     }
 #pragma unroll
@@ -621,17 +603,8 @@ __device__ __forceinline__ void zgemm_flat(double* __restrict__ Cre, double* __r
       const int row = u / (PN / 2), col = (u % (PN / 2)) * 2;
       if (col < ncols) {
         const long long o = (krow + row) * ldb + n0 + col;
-        if (GLDS) {
-          double* d = stage + 2 * G::A_PLANE + 2 * (u_wave + G::WGT * i);
-          __builtin_amdgcn_global_load_lds(Bre + o, (lds_ptr_t)d, 16, 0, 0);
-          __builtin_amdgcn_global_load_lds(Bim + o, (lds_ptr_t)(d + G::B_PLANE), 16, 0, 0);
-        } else if (NTB) {
-          rb[2 * i] = load_stream(Bre + o);
-          rb[2 * i + 1] = load_stream(Bim + o);
-        } else {
-          rb[2 * i] = *reinterpret_cast<const double2*>(Bre + o);
-          rb[2 * i + 1] = *reinterpret_cast<const double2*>(Bim + o);
-        }
+        rb[2 * i] = *reinterpret_cast<const double2*>(Bre + o);
+        rb[2 * i + 1] = *reinterpret_cast<const double2*>(Bim + o);
       }
     }
     if (++f_kt == nk) {
@@ -640,7 +613,6 @@ __device__ __forceinline__ void zgemm_flat(double* __restrict__ Cre, double* __r
     }
   };
   auto stash = [&](int buf) __attribute__((always_inline)) {
-    if (GLDS) return;  // the DMA already wrote the buffer
     double* base = lds + buf * G::STAGE_D;
 #pragma unroll
     for (int i = 0; i < G::UA; ++i) {
@@ -663,9 +635,9 @@ __device__ __forceinline__ void zgemm_flat(double* __restrict__ Cre, double* __r
   int cnt = 0;                       // valid output tiles of this wave in the current pass
   int c_kt = 0, c_pm = 0, c_pn = 0;  // position of the step being COMPUTED
 
-  QK_T(5, { fetch(0); stash(0); __syncthreads(); });
+  QK_T(5, { fetch(); stash(0); __syncthreads(); });
   for (int s = 0; s < total; ++s) {
-    QK_T(0, { if (s + 1 < total) fetch((s + 1) & 1); });
+    QK_T(0, { if (s + 1 < total) fetch(); });
     const int m0 = c_pm * PM, n0 = c_pn * PN;
     if (c_kt == 0) {
       const int mt = min(PM / TILE, (M - m0) / TILE);
@@ -685,7 +657,7 @@ __device__ __forceinline__ void zgemm_flat(double* __restrict__ Cre, double* __r
     const int ksteps = min(KTL / 4, k4 - c_kt * (KTL / 4));
     QK_T(1, {
       if (ksteps == KTL / 4)
-        mma_ktile<CONJB, PM, PN, G::A_PLANE, G::B_PLANE, KTL / 4, G::MAXT, true, PIPE>(cre, cim, tm, tn, base, q, j, cnt, ksteps);
+        mma_ktile<CONJB, PM, PN, G::A_PLANE, G::B_PLANE, KTL / 4, G::MAXT, true>(cre, cim, tm, tn, base, q, j, cnt, ksteps);
       else
         mma_ktile<CONJB, PM, PN, G::A_PLANE, G::B_PLANE, KTL / 4, G::MAXT, false>(cre, cim, tm, tn, base, q, j, cnt, ksteps);
     });
@@ -925,8 +897,8 @@ __global__ __launch_bounds__(64 * NW, OCC) void qk_sweep_deep_kernel(const Sweep
   }
 }
 
-template <int PN, int KTL, bool NTB, int OCC = 2, bool PROF = false, int NW = 4, int PMT = 64, bool GLDS = false>
-__global__ __launch_bounds__(64 * NW, OCC) void qk_sweep_flat_kernel(const SweepArgs g) {
+template <int PN, int KTL, bool PROF = false, int NW = 4, int PMT = 64>
+__global__ __launch_bounds__(64 * NW, 2) void qk_sweep_flat_kernel(const SweepArgs g) {
   using G = GemmCfg<PN, KTL, NW, PMT>;
   extern __shared__ __attribute__((aligned(16))) double lds[];
   long long* slot = reinterpret_cast<long long*>(lds + G::LDS_D);
@@ -967,9 +939,9 @@ __global__ __launch_bounds__(64 * NW, OCC) void qk_sweep_flat_kernel(const Sweep
       const double* Bre = g.ydata + yo[k];
       const double* Bim = Bre + (long long)b * 2 * b2;
       // phase 1: T[a x 2b2] = X^T B, contraction over the TRUE bond b_k of y
-      zgemm_flat<false, PN, KTL, NTB, PROF, (PMT == 64 && (OCC < 3 || NW > 4)), NW, PMT, GLDS>(Tre, Tim, 2 * b2, Xre, Xim, a, Bre, Bim, 2 * b2, a, 2 * b2, yt[k], lds, pc);
+      zgemm_flat<false, PN, KTL, PROF, NW, PMT>(Tre, Tim, 2 * b2, Xre, Xim, a, Bre, Bim, 2 * b2, a, 2 * b2, yt[k], lds, pc);
       // phase 2: X'[b2 x a2] = T^T conj(A), contraction over the 2 * a_k true rows (L, p)
-      zgemm_flat<true, PN, KTL, NTB, PROF, (PMT == 64 && (OCC < 3 || NW > 4)), NW, PMT, GLDS>(Xre, Xim, a2, Tre, Tim, b2, Are, Aim, a2, b2, a2, 2 * xt[k], lds, pc);
+      zgemm_flat<true, PN, KTL, PROF, NW, PMT>(Xre, Xim, a2, Tre, Tim, b2, Are, Aim, a2, b2, a2, 2 * xt[k], lds, pc);
     }
     if (tid == 0) {
       const double re = Xre[0], im = Xim[0];
@@ -1072,25 +1044,16 @@ extern "C" int qk_ctx_create(int device_id, qk_ctx** out) {
   HIP_TRY(hipMalloc(&c->prof, 8 * sizeof(unsigned long long)));
   HIP_TRY(hipMemset(c->prof, 0, 8 * sizeof(unsigned long long)));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(qk_sweep_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES));
-  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(qk_sweep_flat_kernel<64, 8, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)GemmCfg<64, 8>::LDS_B));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(qk_sweep_flat_kernel<64, 16, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)GemmCfg<64, 16>::LDS_B));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(qk_sweep_flat_kernel<64, 16, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)GemmCfg<64, 16>::LDS_B));
-  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(qk_sweep_flat_kernel<64, 16, false, 2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)GemmCfg<64, 16>::LDS_B));
-  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(qk_sweep_flat_kernel<64, 16, false, 4, false, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)GemmCfg<64, 16, 8>::LDS_B));
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(qk_sweep_deep_kernel<64, 16, 2, 4, 64>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)GemmCfg<64, 16, 4>::LDS_B));
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(qk_sweep_deep_kernel<64, 16, 4, 8, 64>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)GemmCfg<64, 16, 8>::LDS_B));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(qk_mma_bench_kernel<64, 16, 4, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)GemmCfg<64, 16, 4, 64>::LDS_B));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(qk_mma_bench_kernel<64, 16, 4, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)GemmCfg<64, 16, 4, 64>::LDS_B));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(qk_mma_bench_kernel<64, 16, 8, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)GemmCfg<64, 16, 4, 64>::LDS_B));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(qk_mma_bench_kernel<64, 16, 8, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)GemmCfg<64, 16, 4, 64>::LDS_B));
-  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(qk_sweep_flat_kernel<64, 16, false, 4, false, 8, 64, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)GemmCfg<64, 16, 8>::LDS_B));
-  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(qk_sweep_flat_kernel<64, 16, false, 2, false, 4, 64, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)GemmCfg<64, 16, 4>::LDS_B));
-  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(qk_sweep_deep_kernel<64, 16, 2, 4, 64>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)GemmCfg<64, 16, 4>::LDS_B));
-  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(qk_sweep_deep_kernel<64, 16, 4, 8, 64>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)GemmCfg<64, 16, 8>::LDS_B));
-  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(qk_sweep_flat_kernel<32, 16, false, 3, false, 4, 64>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)GemmCfg<32, 16, 4, 64>::LDS_B));
-  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(qk_sweep_flat_kernel<128, 8, false, 2, false, 8, 128>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)GemmCfg<128, 8, 8, 128>::LDS_B));
-  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(qk_sweep_flat_kernel<64, 8, false, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)GemmCfg<64, 8>::LDS_B));
-  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(qk_sweep_flat_kernel<64, 8, false, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)GemmCfg<64, 8>::LDS_B));
   if (const char* v = std::getenv("QK_VARIANT")) c->variant = std::atoi(v);
-  if (const char* v = std::getenv("QK_WGS_PER_CU")) c->wgs_per_cu = std::max(1, std::min(4, std::atoi(v)));
+  if (const char* v = std::getenv("QK_WGS_PER_CU")) c->wgs_per_cu = std::max(1, std::min(2, std::atoi(v)));
   *out = c;
   return QK_OK;
 }
@@ -1260,38 +1223,25 @@ extern "C" int qk_gram_values(qk_ctx* c, const qk_mps_set* xs, const qk_mps_set*
   a.prof = c->prof;
   HIP_TRY(hipMemsetAsync(c->counter, 0, sizeof(unsigned long long), c->stream));
   HIP_TRY(hipEventRecord(c->ev0, c->stream));
-  constexpr size_t lds_a = GemmCfg<64, 8>::LDS_B, lds_b = GemmCfg<64, 16>::LDS_B;
-  if (c->variant == 0)
-    qk_sweep_kernel<<<dim3(grid), dim3(WG_THREADS), LDS_BYTES, c->stream>>>(a);
-  else if (c->variant == 2)
-    qk_sweep_flat_kernel<64, 16, false><<<dim3(grid), dim3(WG_THREADS), lds_b, c->stream>>>(a);
-  else if (c->variant == 3)
-    qk_sweep_flat_kernel<64, 16, true><<<dim3(grid), dim3(WG_THREADS), lds_b, c->stream>>>(a);
-  else if (c->variant == 6)
-    qk_sweep_flat_kernel<64, 16, false, 4, false, 8><<<dim3(grid), dim3(512), lds_b, c->stream>>>(a);
-  else if (c->variant == 12)
-    qk_sweep_deep_kernel<64, 16, 2, 4, 64><<<dim3(grid), dim3(256), lds_b, c->stream>>>(a);
-  else if (c->variant == 13)
-    qk_sweep_deep_kernel<64, 16, 4, 8, 64><<<dim3(grid), dim3(512), lds_b, c->stream>>>(a);
-  else if (c->variant == 10)
-    qk_sweep_flat_kernel<64, 16, false, 4, false, 8, 64, true><<<dim3(grid), dim3(512), lds_b, c->stream>>>(a);
-  else if (c->variant == 11)
-    qk_sweep_flat_kernel<64, 16, false, 2, false, 4, 64, true><<<dim3(grid), dim3(256), lds_b, c->stream>>>(a);
-  else if (c->variant == 8) {
-    constexpr size_t lds_d = GemmCfg<32, 16, 4, 64>::LDS_B;
-    qk_sweep_flat_kernel<32, 16, false, 3, false, 4, 64><<<dim3(grid), dim3(256), lds_d, c->stream>>>(a);
-  } else if (c->variant == 7) {
-    constexpr size_t lds_c = GemmCfg<128, 8, 8, 128>::LDS_B;
-    qk_sweep_flat_kernel<128, 8, false, 2, false, 8, 128><<<dim3(grid), dim3(512), lds_c, c->stream>>>(a);
-  } else if (c->variant == 9) {
-    HIP_TRY(hipMemsetAsync(c->prof, 0, 8 * sizeof(unsigned long long), c->stream));
-    qk_sweep_flat_kernel<64, 16, false, 2, true><<<dim3(grid), dim3(WG_THREADS), lds_b, c->stream>>>(a);
-  } else if (c->variant == 4)
-    qk_sweep_flat_kernel<64, 8, false, 3><<<dim3(grid), dim3(WG_THREADS), lds_a, c->stream>>>(a);
-  else if (c->variant == 5)
-    qk_sweep_flat_kernel<64, 8, false, 4><<<dim3(grid), dim3(WG_THREADS), lds_a, c->stream>>>(a);
-  else
-    qk_sweep_flat_kernel<64, 8, false><<<dim3(grid), dim3(WG_THREADS), lds_a, c->stream>>>(a);
+  constexpr size_t lds_b = GemmCfg<64, 16>::LDS_B;
+  switch (c->variant) {
+    case 0:  // v1: per-pass pipeline, 4 waves
+      qk_sweep_kernel<<<dim3(grid), dim3(WG_THREADS), LDS_BYTES, c->stream>>>(a);
+      break;
+    case 2:  // flat pipeline, 4 waves, one-step prefetch
+      qk_sweep_flat_kernel<64, 16, false><<<dim3(grid), dim3(WG_THREADS), lds_b, c->stream>>>(a);
+      break;
+    case 9:  // diagnostic: instrumented flat pipeline (qk_debug_profile)
+      HIP_TRY(hipMemsetAsync(c->prof, 0, 8 * sizeof(unsigned long long), c->stream));
+      qk_sweep_flat_kernel<64, 16, true><<<dim3(grid), dim3(WG_THREADS), lds_b, c->stream>>>(a);
+      break;
+    case 12:  // two-step-deep prefetch, 4 waves
+      qk_sweep_deep_kernel<64, 16, 2, 4, 64><<<dim3(grid), dim3(256), lds_b, c->stream>>>(a);
+      break;
+    default:  // 13: two-step-deep prefetch, 8 waves (2 tiles per wave, 16 waves per CU) -- the shipped kernel
+      qk_sweep_deep_kernel<64, 16, 4, 8, 64><<<dim3(grid), dim3(512), lds_b, c->stream>>>(a);
+      break;
+  }
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipEventRecord(c->ev1, c->stream));
   c->ev_pending = true;
