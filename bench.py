@@ -229,6 +229,15 @@ def main():
     out = None
     if rank == 0:
         achieved = my["flops"] / (kms * 1e-3) / 1e12 if kms > 0 else 0.0
+        # HBM/fabric bytes per launch of the dominant kernel: PMC numbers cannot be collected from inside this
+        # process, so the committed rocprofv3 --pmc summary of the SAME workload (profiles/run_rocprof.sh) is quoted.
+        traffic = None
+        pmc_file = os.path.join(ROOT, "profiles", "r01", "pmc_summary.json")
+        if world == 1 and args.config == "cfg4" and args.gamma == 1.0 and not args.points and args.seed == 5 and os.path.exists(pmc_file):
+            try:
+                traffic = json.load(open(pmc_file))["derived"]["traffic_bytes_per_launch"]
+            except (KeyError, ValueError):
+                traffic = None
         out = {
             "metric": "Gram kernel entries/sec @ 60 qubits x 6 layers" if args.config == "cfg4" else f"Gram kernel entries/sec @ {n} qubits x {reps} layers",
             "value": npts * npts / (ms_per_step * 1e-3),
@@ -256,12 +265,13 @@ def main():
             },
             "roofline": {
                 "bound": "mfma",
-                "kernel": "qk_sweep_kernel",
+                "kernel": "qk_sweep_deep_kernel<64,16,4,8,64>",
                 "achieved": achieved,
                 "peak": PEAK_F64_MFMA_TFLOPS,
                 "unit": "TFLOP/s",
                 "frac": achieved / PEAK_F64_MFMA_TFLOPS,
-                "traffic": None,
+                "traffic": traffic,
+                "traffic_source": "profiles/r01/pmc_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, FETCH_SIZE x2 gfx950 correction), bytes per launch" if traffic else None,
                 "kernel_ms": kms,
                 "algorithmic_tflop_per_launch": my["flops"] / 1e12,
                 "executed_padded_tflop_per_launch": my["padded_flops"] / 1e12,
