@@ -698,11 +698,11 @@ __device__ __forceinline__ void zgemm_flat(double* __restrict__ Cre, double* __r
 // (a __syncthreads() would wait vmcnt(0) and cancel the prefetch that is meant to stay in flight).
 __device__ __forceinline__ void qk_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-template <bool CONJB, int PN, int KTL, int NW, int PMT>
+template <bool CONJB, int PN, int KTL, int NW, int PMT, bool PROF = false>
 __device__ __forceinline__ void zgemm_deep(double* __restrict__ Cre, double* __restrict__ Cim, const int ldc,
                                            const double* __restrict__ Are, const double* __restrict__ Aim, const int lda,
                                            const double* __restrict__ Bre, const double* __restrict__ Bim, const int ldb,
-                                           const int M, const int N, const int Ktrue, double* __restrict__ lds) {
+                                           const int M, const int N, const int Ktrue, double* __restrict__ lds, long long (&pc)[8]) {
   using G = GemmCfg<PN, KTL, NW, PMT>;
   constexpr int PM = G::PM;
   const int tid = threadIdx.x;
@@ -813,39 +813,45 @@ __device__ __forceinline__ void zgemm_deep(double* __restrict__ Cre, double* __r
   };
 
   // prologue: tiles 0 and 1 in flight, tile 0 published
-  QK_FETCH_SET(ra0, rb0);
-  if (total > 1) QK_FETCH_SET(ra1, rb1);
-  QK_STASH_SET(0, ra0, rb0);
-  qk_lds_barrier();
+  QK_T(5, {
+    QK_FETCH_SET(ra0, rb0);
+    if (total > 1) QK_FETCH_SET(ra1, rb1);
+    QK_STASH_SET(0, ra0, rb0);
+    qk_lds_barrier();
+  });
   int s = 0;
   while (s + 3 < total) {  // tiles s+2 and s+3 exist: both fetches unconditional
-    QK_FETCH_SET(ra0, rb0);        // tile s+2
-    compute_step(0);               // tile s     (s is even here)
-    QK_STASH_SET(1, ra1, rb1);     // tile s+1, fetched two steps ago
-    qk_lds_barrier();
-    QK_FETCH_SET(ra1, rb1);        // tile s+3
-    compute_step(1);               // tile s+1
-    QK_STASH_SET(0, ra0, rb0);     // tile s+2
-    qk_lds_barrier();
+    QK_T(0, QK_FETCH_SET(ra0, rb0));     // tile s+2
+    QK_T(1, compute_step(0));            // tile s     (s is even here)
+    QK_T(3, QK_STASH_SET(1, ra1, rb1));  // tile s+1, fetched two steps ago
+    QK_T(4, qk_lds_barrier());
+    QK_T(0, QK_FETCH_SET(ra1, rb1));     // tile s+3
+    QK_T(1, compute_step(1));            // tile s+1
+    QK_T(3, QK_STASH_SET(0, ra0, rb0));  // tile s+2
+    QK_T(4, qk_lds_barrier());
     s += 2;
   }
   for (; s < total; ++s) {  // tail (at most 3 steps); s keeps its parity convention
     const bool even = (s & 1) == 0;
-    if (s + 2 < total) {
-      if (even) QK_FETCH_SET(ra0, rb0); else QK_FETCH_SET(ra1, rb1);
-    }
-    compute_step(s & 1);
-    if (s + 1 < total) {
-      if (even) QK_STASH_SET(1, ra1, rb1); else QK_STASH_SET(0, ra0, rb0);
-    }
-    qk_lds_barrier();
+    QK_T(0, {
+      if (s + 2 < total) {
+        if (even) QK_FETCH_SET(ra0, rb0); else QK_FETCH_SET(ra1, rb1);
+      }
+    });
+    QK_T(1, compute_step(s & 1));
+    QK_T(3, {
+      if (s + 1 < total) {
+        if (even) QK_STASH_SET(1, ra1, rb1); else QK_STASH_SET(0, ra0, rb0);
+      }
+    });
+    QK_T(4, qk_lds_barrier());
   }
 #undef QK_FETCH_SET
 #undef QK_STASH_SET
-  __syncthreads();
+  QK_T(6, __syncthreads());
 }
 
-template <int PN, int KTL, int OCC, int NW, int PMT>
+template <int PN, int KTL, int OCC, int NW, int PMT, bool PROF = false>
 __global__ __launch_bounds__(64 * NW, OCC) void qk_sweep_deep_kernel(const SweepArgs g) {
   using G = GemmCfg<PN, KTL, NW, PMT>;
   extern __shared__ __attribute__((aligned(16))) double lds[];
@@ -855,6 +861,8 @@ __global__ __launch_bounds__(64 * NW, OCC) void qk_sweep_deep_kernel(const Sweep
   double* Tre = Xim + g.x_plane;
   double* Tim = Tre + g.t_plane;
   const int tid = threadIdx.x;
+  long long pc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  const long long t_begin = PROF ? qk_stamp() : 0;
   for (;;) {
     if (tid == 0) *slot = (long long)atomicAdd(g.counter, 1ull);
     __syncthreads();
@@ -882,8 +890,8 @@ __global__ __launch_bounds__(64 * NW, OCC) void qk_sweep_deep_kernel(const Sweep
       const double* Aim = Are + (long long)a * 2 * a2;
       const double* Bre = g.ydata + yo[k];
       const double* Bim = Bre + (long long)b * 2 * b2;
-      zgemm_deep<false, PN, KTL, NW, PMT>(Tre, Tim, 2 * b2, Xre, Xim, a, Bre, Bim, 2 * b2, a, 2 * b2, yt[k], lds);
-      zgemm_deep<true, PN, KTL, NW, PMT>(Xre, Xim, a2, Tre, Tim, b2, Are, Aim, a2, b2, a2, 2 * xt[k], lds);
+      zgemm_deep<false, PN, KTL, NW, PMT, PROF>(Tre, Tim, 2 * b2, Xre, Xim, a, Bre, Bim, 2 * b2, a, 2 * b2, yt[k], lds, pc);
+      zgemm_deep<true, PN, KTL, NW, PMT, PROF>(Xre, Xim, a2, Tre, Tim, b2, Are, Aim, a2, b2, a2, 2 * xt[k], lds, pc);
     }
     if (tid == 0) {
       const double re = Xre[0], im = Xim[0];
@@ -894,6 +902,11 @@ __global__ __launch_bounds__(64 * NW, OCC) void qk_sweep_deep_kernel(const Sweep
       }
     }
     __syncthreads();
+  }
+  if (PROF && g.prof && (tid & 63) == 0) {
+    pc[7] = qk_stamp() - t_begin;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) atomicAdd(g.prof + c, (unsigned long long)pc[c]);
   }
 }
 
@@ -1048,6 +1061,7 @@ extern "C" int qk_ctx_create(int device_id, qk_ctx** out) {
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(qk_sweep_flat_kernel<64, 16, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)GemmCfg<64, 16>::LDS_B));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(qk_sweep_deep_kernel<64, 16, 2, 4, 64>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)GemmCfg<64, 16, 4>::LDS_B));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(qk_sweep_deep_kernel<64, 16, 4, 8, 64>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)GemmCfg<64, 16, 8>::LDS_B));
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(qk_sweep_deep_kernel<64, 16, 4, 8, 64, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)GemmCfg<64, 16, 8>::LDS_B));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(qk_mma_bench_kernel<64, 16, 4, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)GemmCfg<64, 16, 4, 64>::LDS_B));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(qk_mma_bench_kernel<64, 16, 4, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)GemmCfg<64, 16, 4, 64>::LDS_B));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(qk_mma_bench_kernel<64, 16, 8, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)GemmCfg<64, 16, 4, 64>::LDS_B));
@@ -1234,6 +1248,10 @@ extern "C" int qk_gram_values(qk_ctx* c, const qk_mps_set* xs, const qk_mps_set*
     case 9:  // diagnostic: instrumented flat pipeline (qk_debug_profile)
       HIP_TRY(hipMemsetAsync(c->prof, 0, 8 * sizeof(unsigned long long), c->stream));
       qk_sweep_flat_kernel<64, 16, true><<<dim3(grid), dim3(WG_THREADS), lds_b, c->stream>>>(a);
+      break;
+    case 19:  // diagnostic: instrumented shipped kernel
+      HIP_TRY(hipMemsetAsync(c->prof, 0, 8 * sizeof(unsigned long long), c->stream));
+      qk_sweep_deep_kernel<64, 16, 4, 8, 64, true><<<dim3(grid), dim3(512), lds_b, c->stream>>>(a);
       break;
     case 12:  // two-step-deep prefetch, 4 waves
       qk_sweep_deep_kernel<64, 16, 2, 4, 64><<<dim3(grid), dim3(256), lds_b, c->stream>>>(a);

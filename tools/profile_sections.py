@@ -1,10 +1,10 @@
 #!/usr/bin/env python3
 """Section shares of the instrumented sweep kernel (QK_VARIANT=9) on the cfg4 workload (or a uniform-chi set).
-usage: QK_VARIANT=9 python tools/profile_sections.py [chi]"""
+usage: [QK_VARIANT=19|9] python tools/profile_sections.py [chi]   (19 = instrumented shipped kernel, 9 = 4-wave flat)"""
 import os, pickle, sys, glob
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-os.environ["QK_VARIANT"] = "9"
+os.environ.setdefault("QK_VARIANT", "19")
 import qml_cutensornet_amd as Q
 from qml_cutensornet_amd import engine
 
