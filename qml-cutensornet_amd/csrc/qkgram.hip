@@ -722,28 +722,42 @@ __device__ __forceinline__ void zgemm_deep(double* __restrict__ Cre, double* __r
   for (int i = 0; i < 2 * G::UB; ++i) rb0[i] = rb1[i] = make_double2(0.0, 0.0);
 
   int f_kt = 0, f_pm = 0, f_pn = 0;
+  // Per-thread staging coordinates are fixed for the whole GEMM: row offset (in elements) and
+  // column of each 16-byte unit.  Per step only a wave-uniform base (SGPR pair) changes, so a load
+  // costs a clamp, an add and the instruction itself instead of 64-bit per-lane address math.
+  unsigned rowoffA[G::UA], rowoffB[G::UB];
+  int colA[G::UA], colB[G::UB];
+#pragma unroll
+  for (int i = 0; i < G::UA; ++i) {
+    const int u = tid + G::WGT * i;
+    rowoffA[i] = (unsigned)((u / (PM / 2)) * lda);
+    colA[i] = (u % (PM / 2)) * 2;
+  }
+#pragma unroll
+  for (int i = 0; i < G::UB; ++i) {
+    const int u = tid + G::WGT * i;
+    rowoffB[i] = (unsigned)((u / (PN / 2)) * ldb);
+    colB[i] = (u % (PN / 2)) * 2;
+  }
 #define QK_FETCH_SET(RA, RB)                                                      \
   do {                                                                            \
     const int m0_ = f_pm * PM, n0_ = f_pn * PN;                                   \
     const int mcols_ = min(PM, M - m0_), ncols_ = min(PN, N - n0_);               \
-    const long long krow_ = (long long)f_kt * KTL;                                \
+    const long long ka_ = (long long)f_kt * KTL * lda + m0_;                      \
+    const long long kb_ = (long long)f_kt * KTL * ldb + n0_;                      \
+    const double* are_ = Are + ka_;                                               \
+    const double* aim_ = Aim + ka_;                                               \
+    const double* bre_ = Bre + kb_;                                               \
+    const double* bim_ = Bim + kb_;                                               \
     _Pragma("unroll") for (int i = 0; i < G::UA; ++i) {                           \
-      const int u = tid + G::WGT * i;                                             \
-      const int row = u / (PM / 2), col = min((u % (PM / 2)) * 2, mcols_ - 2);    \
-      {                                                                           \
-        const long long o = (krow_ + row) * lda + m0_ + col;                      \
-        RA[2 * i] = *reinterpret_cast<const double2*>(Are + o);                   \
-        RA[2 * i + 1] = *reinterpret_cast<const double2*>(Aim + o);               \
-      }                                                                           \
+      const unsigned o = rowoffA[i] + (unsigned)min(colA[i], mcols_ - 2);         \
+      RA[2 * i] = *reinterpret_cast<const double2*>(are_ + o);                    \
+      RA[2 * i + 1] = *reinterpret_cast<const double2*>(aim_ + o);                \
     }                                                                             \
     _Pragma("unroll") for (int i = 0; i < G::UB; ++i) {                           \
-      const int u = tid + G::WGT * i;                                             \
-      const int row = u / (PN / 2), col = min((u % (PN / 2)) * 2, ncols_ - 2);    \
-      {                                                                           \
-        const long long o = (krow_ + row) * ldb + n0_ + col;                      \
-        RB[2 * i] = *reinterpret_cast<const double2*>(Bre + o);                   \
-        RB[2 * i + 1] = *reinterpret_cast<const double2*>(Bim + o);               \
-      }                                                                           \
+      const unsigned o = rowoffB[i] + (unsigned)min(colB[i], ncols_ - 2);         \
+      RB[2 * i] = *reinterpret_cast<const double2*>(bre_ + o);                    \
+      RB[2 * i + 1] = *reinterpret_cast<const double2*>(bim_ + o);                \
     }                                                                             \
     if (++f_kt == nk) {                                                           \
       f_kt = 0;                                                                   \
@@ -870,14 +884,35 @@ __global__ __launch_bounds__(64 * NW, OCC) void qk_sweep_deep_kernel(const Sweep
     __syncthreads();
     if (p >= g.npairs) break;
     const int xi = g.pairs[2 * p], yj = g.pairs[2 * p + 1];
-    const int32_t* xd = g.xdims + (long long)xi * (g.n_sites + 1);
-    const int32_t* yd = g.ydims + (long long)yj * (g.n_sites + 1);
-    const int32_t* xt = g.xtrue + (long long)xi * (g.n_sites + 1);
-    const int32_t* yt = g.ytrue + (long long)yj * (g.n_sites + 1);
-    const int64_t* xo = g.xoffs + (long long)xi * g.n_sites;
-    const int64_t* yo = g.yoffs + (long long)yj * g.n_sites;
+    // Stage the pair's per-site metadata in LDS once (one coalesced pass) instead of chasing it
+    // through global memory at every site: [xd | yd | xt | yt] (n+1 ints each) then [xo | yo] (n int64).
+    const int n1 = g.n_sites + 1;
+    int* m_xd = reinterpret_cast<int*>(slot + 2);
+    int* m_yd = m_xd + n1;
+    int* m_xt = m_yd + n1;
+    int* m_yt = m_xt + n1;
+    long long* m_xo = reinterpret_cast<long long*>(m_xd + 4 * n1 + (4 * n1 & 1));
+    long long* m_yo = m_xo + g.n_sites;
+    for (int e = tid; e < n1; e += 64 * NW) {
+      m_xd[e] = g.xdims[(long long)xi * n1 + e];
+      m_yd[e] = g.ydims[(long long)yj * n1 + e];
+      m_xt[e] = g.xtrue[(long long)xi * n1 + e];
+      m_yt[e] = g.ytrue[(long long)yj * n1 + e];
+      if (e < g.n_sites) {
+        m_xo[e] = g.xoffs[(long long)xi * g.n_sites + e];
+        m_yo[e] = g.yoffs[(long long)yj * g.n_sites + e];
+      }
+    }
+    __syncthreads();
+    auto ldi = [&](const int* q_) __attribute__((always_inline)) { return __builtin_amdgcn_readfirstlane(*q_); };
+    auto ldl = [&](const long long* q_) __attribute__((always_inline)) {
+      const long long v = *q_;
+      const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v);
+      const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)((unsigned long long)v >> 32));
+      return (long long)(((unsigned long long)hi << 32) | lo);
+    };
     {
-      const int a = xd[0], b = yd[0];
+      const int a = ldi(m_xd), b = ldi(m_yd);
       for (int e = tid; e < a * b; e += 64 * NW) {
         Xre[e] = (e == 0) ? 1.0 : 0.0;
         Xim[e] = 0.0;
@@ -885,13 +920,13 @@ __global__ __launch_bounds__(64 * NW, OCC) void qk_sweep_deep_kernel(const Sweep
       __syncthreads();
     }
     for (int k = 0; k < g.n_sites; ++k) {
-      const int a = xd[k], a2 = xd[k + 1], b = yd[k], b2 = yd[k + 1];
-      const double* Are = g.xdata + xo[k];
+      const int a = ldi(m_xd + k), a2 = ldi(m_xd + k + 1), b = ldi(m_yd + k), b2 = ldi(m_yd + k + 1);
+      const double* Are = g.xdata + ldl(m_xo + k);
       const double* Aim = Are + (long long)a * 2 * a2;
-      const double* Bre = g.ydata + yo[k];
+      const double* Bre = g.ydata + ldl(m_yo + k);
       const double* Bim = Bre + (long long)b * 2 * b2;
-      zgemm_deep<false, PN, KTL, NW, PMT, PROF>(Tre, Tim, 2 * b2, Xre, Xim, a, Bre, Bim, 2 * b2, a, 2 * b2, yt[k], lds, pc);
-      zgemm_deep<true, PN, KTL, NW, PMT, PROF>(Xre, Xim, a2, Tre, Tim, b2, Are, Aim, a2, b2, a2, 2 * xt[k], lds, pc);
+      zgemm_deep<false, PN, KTL, NW, PMT, PROF>(Tre, Tim, 2 * b2, Xre, Xim, a, Bre, Bim, 2 * b2, a, 2 * b2, ldi(m_yt + k), lds, pc);
+      zgemm_deep<true, PN, KTL, NW, PMT, PROF>(Xre, Xim, a2, Tre, Tim, b2, Are, Aim, a2, b2, a2, 2 * ldi(m_xt + k), lds, pc);
     }
     if (tid == 0) {
       const double re = Xre[0], im = Xim[0];
@@ -1059,9 +1094,9 @@ extern "C" int qk_ctx_create(int device_id, qk_ctx** out) {
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(qk_sweep_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(qk_sweep_flat_kernel<64, 16, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)GemmCfg<64, 16>::LDS_B));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(qk_sweep_flat_kernel<64, 16, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)GemmCfg<64, 16>::LDS_B));
-  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(qk_sweep_deep_kernel<64, 16, 2, 4, 64>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)GemmCfg<64, 16, 4>::LDS_B));
-  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(qk_sweep_deep_kernel<64, 16, 4, 8, 64>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)GemmCfg<64, 16, 8>::LDS_B));
-  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(qk_sweep_deep_kernel<64, 16, 4, 8, 64, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)GemmCfg<64, 16, 8>::LDS_B));
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(qk_sweep_deep_kernel<64, 16, 2, 4, 64>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(qk_sweep_deep_kernel<64, 16, 4, 8, 64>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(qk_sweep_deep_kernel<64, 16, 4, 8, 64, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(qk_mma_bench_kernel<64, 16, 4, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)GemmCfg<64, 16, 4, 64>::LDS_B));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(qk_mma_bench_kernel<64, 16, 4, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)GemmCfg<64, 16, 4, 64>::LDS_B));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(qk_mma_bench_kernel<64, 16, 8, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)GemmCfg<64, 16, 4, 64>::LDS_B));
@@ -1238,6 +1273,9 @@ extern "C" int qk_gram_values(qk_ctx* c, const qk_mps_set* xs, const qk_mps_set*
   HIP_TRY(hipMemsetAsync(c->counter, 0, sizeof(unsigned long long), c->stream));
   HIP_TRY(hipEventRecord(c->ev0, c->stream));
   constexpr size_t lds_b = GemmCfg<64, 16>::LDS_B;
+  // deep kernels also keep the pair's per-site metadata in LDS: 4 (n+1) ints + 2 n int64 (+ alignment)
+  const size_t lds_deep = lds_b + 16 + (size_t)(4 * (xs->n_sites + 1) + 2) * sizeof(int) + (size_t)2 * xs->n_sites * sizeof(long long);
+  if (lds_deep > 80 * 1024) return fail(QK_EINVAL, "qk_gram_values: %d sites need %zu bytes of LDS per workgroup (limit 80 KiB for 2 workgroups per CU)", xs->n_sites, lds_deep);
   switch (c->variant) {
     case 0:  // v1: per-pass pipeline, 4 waves
       qk_sweep_kernel<<<dim3(grid), dim3(WG_THREADS), LDS_BYTES, c->stream>>>(a);
@@ -1251,13 +1289,13 @@ extern "C" int qk_gram_values(qk_ctx* c, const qk_mps_set* xs, const qk_mps_set*
       break;
     case 19:  // diagnostic: instrumented shipped kernel
       HIP_TRY(hipMemsetAsync(c->prof, 0, 8 * sizeof(unsigned long long), c->stream));
-      qk_sweep_deep_kernel<64, 16, 4, 8, 64, true><<<dim3(grid), dim3(512), lds_b, c->stream>>>(a);
+      qk_sweep_deep_kernel<64, 16, 4, 8, 64, true><<<dim3(grid), dim3(512), lds_deep, c->stream>>>(a);
       break;
     case 12:  // two-step-deep prefetch, 4 waves
-      qk_sweep_deep_kernel<64, 16, 2, 4, 64><<<dim3(grid), dim3(256), lds_b, c->stream>>>(a);
+      qk_sweep_deep_kernel<64, 16, 2, 4, 64><<<dim3(grid), dim3(256), lds_deep, c->stream>>>(a);
       break;
     default:  // 13: two-step-deep prefetch, 8 waves (2 tiles per wave, 16 waves per CU) -- the shipped kernel
-      qk_sweep_deep_kernel<64, 16, 4, 8, 64><<<dim3(grid), dim3(512), lds_b, c->stream>>>(a);
+      qk_sweep_deep_kernel<64, 16, 4, 8, 64><<<dim3(grid), dim3(512), lds_deep, c->stream>>>(a);
       break;
   }
   HIP_TRY(hipGetLastError());
