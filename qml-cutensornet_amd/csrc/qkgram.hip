@@ -86,11 +86,14 @@ struct qk_plan {
   bool symmetric = false;
   int world = 1, rank = 0;
   int64_t total_pairs = 0, max_per_rank = 0;
-  std::vector<int32_t> pairs;  // this rank, (i, j) interleaved
+  std::vector<int32_t> pairs;   // this rank, (i, j) interleaved
+  std::vector<int32_t> groups;  // (first pair, count): runs of <= group pairs that share the x state
+  int group = 1;
   qk_stats stats{};
   // lazily uploaded copy
   qk_ctx* up_ctx = nullptr;
   int32_t* d_pairs = nullptr;
+  int32_t* d_groups = nullptr;
 };
 
 // ----------------------------------------------------------------------------------------
@@ -203,6 +206,47 @@ extern "C" int qk_plan_create(int32_t n_sites, int32_t nx, const int32_t* x_dims
         ++t;
       }
     }
+  // Regroup this rank's share: pairs that share the x state are made contiguous and cut into
+  // groups of at most QK_GROUP (default 4) pairs -- one workgroup sweeps a group in lockstep so
+  // that A_i is read once per group and the per-phase latencies are shared.  Groups are then
+  // ordered by decreasing cost (longest first for the device-side queue).
+  {
+    int G = 4;
+    if (const char* e = std::getenv("QK_GROUP")) G = std::max(1, std::min(4, std::atoi(e)));
+    p->group = G;
+    const int64_t np = (int64_t)p->pairs.size() / 2;
+    std::vector<Item> mine((size_t)np);
+    for (int64_t q = 0; q < np; ++q) {
+      double f, fp, by;
+      const int i = p->pairs[2 * q], j = p->pairs[2 * q + 1];
+      pair_work(n_sites, x_dims + (int64_t)i * stride, y_dims + (int64_t)j * stride, &f, &fp, &by);
+      mine[(size_t)q] = {i, j, (float)fp};
+    }
+    std::stable_sort(mine.begin(), mine.end(), [](const Item& u, const Item& v) { return u.i != v.i ? u.i < v.i : u.cost > v.cost; });
+    struct Grp {
+      int64_t start;
+      int count;
+      double cost;
+    };
+    std::vector<Grp> grp;
+    for (int64_t q = 0; q < np;) {
+      int c = 1;
+      double cost = mine[(size_t)q].cost;
+      while (c < G && q + c < np && mine[(size_t)(q + c)].i == mine[(size_t)q].i) cost += mine[(size_t)(q + c)].cost, ++c;
+      grp.push_back({q, c, cost});
+      q += c;
+    }
+    std::stable_sort(grp.begin(), grp.end(), [](const Grp& u, const Grp& v) { return u.cost > v.cost; });
+    p->pairs.clear();
+    for (const Grp& gq : grp) {
+      p->groups.push_back((int32_t)(p->pairs.size() / 2));
+      p->groups.push_back(gq.count);
+      for (int c = 0; c < gq.count; ++c) {
+        p->pairs.push_back(mine[(size_t)(gq.start + c)].i);
+        p->pairs.push_back(mine[(size_t)(gq.start + c)].j);
+      }
+    }
+  }
   p->total_pairs = t;
   p->max_per_rank = *std::max_element(per_rank.begin(), per_rank.end());
   p->stats.pairs = (int64_t)p->pairs.size() / 2;
@@ -214,6 +258,7 @@ extern "C" int qk_plan_create(int32_t n_sites, int32_t nx, const int32_t* x_dims
 extern "C" int qk_plan_destroy(qk_plan* plan) {
   if (!plan) return QK_OK;
   if (plan->d_pairs) (void)hipFree(plan->d_pairs);
+  if (plan->d_groups) (void)hipFree(plan->d_groups);
   delete plan;
   return QK_OK;
 }
@@ -254,6 +299,8 @@ struct SweepArgs {
   int n_sites;
   const int32_t* pairs;
   long long npairs;
+  const int32_t* groups;  // (first pair, count) per group
+  long long ngroups;
   double* values;
   double* z;
   double* scratch;
@@ -945,6 +992,333 @@ __global__ __launch_bounds__(64 * NW, OCC) void qk_sweep_deep_kernel(const Sweep
   }
 }
 
+// ----------------------------------------------------------------------------------------
+// v4: group sweep.  One workgroup carries up to GMAX pairs that share the x state through the
+// sweep in lockstep.  Per site:
+//   phase 1  = a STREAM of 2*cnt independent GEMMs  T_g,p[a x b'_g] = X_g^T B_g,p   (p = physical index)
+//              written into one stacked matrix T_all[(L,p)][sum_g b'_g];
+//   phase 2  = ONE GEMM  X'_all[sum_g b'_g x a'] = T_all^T conj(A_k)  (A_k read once per group).
+// zgemm_stream runs the two-step-deep prefetch pipeline of zgemm_deep over a list of GEMM
+// descriptors without draining between them, so the fixed per-phase latencies (prologue, barriers,
+// store->load round trip) are paid once per GROUP-phase while the MFMA work grows with the group.
+// ----------------------------------------------------------------------------------------
+static constexpr int GMAX = 4;
+
+struct GemmDesc {  // lives in LDS; planes: im = re + plane
+  double* Cre;
+  const double* Are;
+  const double* Bre;
+  long long c_plane, a_plane, b_plane;
+  int ldc, lda, ldb, M, N, Ktrue;
+};
+
+__device__ __forceinline__ long long qk_uniform_ll(long long v) {
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v);
+  const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)((unsigned long long)v >> 32));
+  return (long long)(((unsigned long long)hi << 32) | lo);
+}
+__device__ __forceinline__ int qk_uniform_i(int v) { return __builtin_amdgcn_readfirstlane(v); }
+
+template <bool CONJB, int PN, int KTL, int NW, int PMT>
+__device__ __forceinline__ void zgemm_stream(const GemmDesc* __restrict__ descs, const int count, double* __restrict__ lds) {
+  using G = GemmCfg<PN, KTL, NW, PMT>;
+  constexpr int PM = G::PM;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int j = lane & 15, q = lane >> 4;
+
+  // total number of (gemm, pass, K-tile) steps
+  int total = 0;
+  for (int g = 0; g < count; ++g) {
+    const int M = qk_uniform_i(descs[g].M), N = qk_uniform_i(descs[g].N), K = qk_uniform_i(descs[g].Ktrue);
+    total += ((M + PM - 1) / PM) * ((N + PN - 1) / PN) * ((K + KTL - 1) / KTL);
+  }
+
+  // ---- fetch-side iterator (runs two steps ahead)
+  int f_g = 0, f_kt = 0, f_pm = 0, f_pn = 0;
+  const double *fAre, *fAim, *fBre, *fBim;
+  int f_lda, f_ldb, f_M, f_N, f_nk, f_npm, f_npn;
+  unsigned rowoffA[G::UA], rowoffB[G::UB];
+  int colA[G::UA], colB[G::UB];
+#pragma unroll
+  for (int i = 0; i < G::UA; ++i) colA[i] = ((tid + G::WGT * i) % (PM / 2)) * 2;
+#pragma unroll
+  for (int i = 0; i < G::UB; ++i) colB[i] = ((tid + G::WGT * i) % (PN / 2)) * 2;
+  auto load_fetch_desc = [&](int g) __attribute__((always_inline)) {
+    const GemmDesc* d = descs + g;
+    fAre = reinterpret_cast<const double*>(qk_uniform_ll(reinterpret_cast<long long>(d->Are)));
+    fAim = fAre + qk_uniform_ll(d->a_plane);
+    fBre = reinterpret_cast<const double*>(qk_uniform_ll(reinterpret_cast<long long>(d->Bre)));
+    fBim = fBre + qk_uniform_ll(d->b_plane);
+    f_lda = qk_uniform_i(d->lda), f_ldb = qk_uniform_i(d->ldb);
+    f_M = qk_uniform_i(d->M), f_N = qk_uniform_i(d->N);
+    f_nk = (qk_uniform_i(d->Ktrue) + KTL - 1) / KTL;
+    f_npm = (f_M + PM - 1) / PM, f_npn = (f_N + PN - 1) / PN;
+#pragma unroll
+    for (int i = 0; i < G::UA; ++i) rowoffA[i] = (unsigned)(((tid + G::WGT * i) / (PM / 2)) * f_lda);
+#pragma unroll
+    for (int i = 0; i < G::UB; ++i) rowoffB[i] = (unsigned)(((tid + G::WGT * i) / (PN / 2)) * f_ldb);
+  };
+  load_fetch_desc(0);
+
+  double2 ra0[2 * G::UA], rb0[2 * G::UB], ra1[2 * G::UA], rb1[2 * G::UB];
+#pragma unroll
+  for (int i = 0; i < 2 * G::UA; ++i) ra0[i] = ra1[i] = make_double2(0.0, 0.0);
+#pragma unroll
+  for (int i = 0; i < 2 * G::UB; ++i) rb0[i] = rb1[i] = make_double2(0.0, 0.0);
+
+#define QK_FETCH_SET(RA, RB)                                                      \
+  do {                                                                            \
+    const int m0_ = f_pm * PM, n0_ = f_pn * PN;                                   \
+    const int mcols_ = min(PM, f_M - m0_), ncols_ = min(PN, f_N - n0_);           \
+    const long long ka_ = (long long)f_kt * KTL * f_lda + m0_;                    \
+    const long long kb_ = (long long)f_kt * KTL * f_ldb + n0_;                    \
+    const double* are_ = fAre + ka_;                                              \
+    const double* aim_ = fAim + ka_;                                              \
+    const double* bre_ = fBre + kb_;                                              \
+    const double* bim_ = fBim + kb_;                                              \
+    _Pragma("unroll") for (int i = 0; i < G::UA; ++i) {                           \
+      const unsigned o = rowoffA[i] + (unsigned)min(colA[i], mcols_ - 2);         \
+      RA[2 * i] = *reinterpret_cast<const double2*>(are_ + o);                    \
+      RA[2 * i + 1] = *reinterpret_cast<const double2*>(aim_ + o);                \
+    }                                                                             \
+    _Pragma("unroll") for (int i = 0; i < G::UB; ++i) {                           \
+      const unsigned o = rowoffB[i] + (unsigned)min(colB[i], ncols_ - 2);         \
+      RB[2 * i] = *reinterpret_cast<const double2*>(bre_ + o);                    \
+      RB[2 * i + 1] = *reinterpret_cast<const double2*>(bim_ + o);                \
+    }                                                                             \
+    if (++f_kt == f_nk) {                                                         \
+      f_kt = 0;                                                                   \
+      if (++f_pm == f_npm) {                                                      \
+        f_pm = 0;                                                                 \
+        if (++f_pn == f_npn) {                                                    \
+          f_pn = 0;                                                               \
+          if (++f_g < count) load_fetch_desc(f_g);                                \
+        }                                                                         \
+      }                                                                           \
+    }                                                                             \
+  } while (0)
+#define QK_STASH_SET(BUF, RA, RB)                                                 \
+  do {                                                                            \
+    double* base_ = lds + (BUF)*G::STAGE_D;                                       \
+    _Pragma("unroll") for (int i = 0; i < G::UA; ++i) {                           \
+      const int u = tid + G::WGT * i;                                             \
+      const int o = (u / (PM / 2)) * PM + (u % (PM / 2)) * 2;                     \
+      *reinterpret_cast<double2*>(base_ + o) = RA[2 * i];                         \
+      *reinterpret_cast<double2*>(base_ + G::A_PLANE + o) = RA[2 * i + 1];        \
+    }                                                                             \
+    _Pragma("unroll") for (int i = 0; i < G::UB; ++i) {                           \
+      const int u = tid + G::WGT * i;                                             \
+      const int o = (u / (PN / 2)) * PN + (u % (PN / 2)) * 2;                     \
+      *reinterpret_cast<double2*>(base_ + 2 * G::A_PLANE + o) = RB[2 * i];        \
+      *reinterpret_cast<double2*>(base_ + 2 * G::A_PLANE + G::B_PLANE + o) = RB[2 * i + 1]; \
+    }                                                                             \
+  } while (0)
+
+  // ---- compute-side iterator
+  int c_g = 0, c_kt = 0, c_pm = 0, c_pn = 0;
+  double *cCre, *cCim;
+  int c_ldc, c_M, c_N, c_nk, c_k4, c_npm, c_npn;
+  auto load_compute_desc = [&](int g) __attribute__((always_inline)) {
+    const GemmDesc* d = descs + g;
+    cCre = reinterpret_cast<double*>(qk_uniform_ll(reinterpret_cast<long long>(d->Cre)));
+    cCim = cCre + qk_uniform_ll(d->c_plane);
+    c_ldc = qk_uniform_i(d->ldc);
+    c_M = qk_uniform_i(d->M), c_N = qk_uniform_i(d->N);
+    const int K = qk_uniform_i(d->Ktrue);
+    c_nk = (K + KTL - 1) / KTL, c_k4 = (K + 3) >> 2;
+    c_npm = (c_M + PM - 1) / PM, c_npn = (c_N + PN - 1) / PN;
+  };
+  load_compute_desc(0);
+
+  v4d cre[G::MAXT], cim[G::MAXT];
+  int tm[G::MAXT], tn[G::MAXT];
+  int cnt = 0;
+  auto compute_step = [&](int buf) __attribute__((always_inline)) {
+    const int m0 = c_pm * PM, n0 = c_pn * PN;
+    if (c_kt == 0) {
+      const int mt = min(PM / TILE, (c_M - m0) / TILE);
+      const int nt = min(PN / TILE, (c_N - n0) / TILE);
+      const int vt = mt * nt;
+      cnt = (vt > wave) ? (vt - wave + NW - 1) / NW : 0;
+#pragma unroll
+      for (int e = 0; e < G::MAXT; ++e) {
+        cre[e] = (v4d){0, 0, 0, 0};
+        cim[e] = (v4d){0, 0, 0, 0};
+        const int t = min(wave + NW * e, vt - 1);
+        tm[e] = t % mt;
+        tn[e] = t / mt;
+      }
+    }
+    const double* base = lds + buf * G::STAGE_D;
+    const int ksteps = min(KTL / 4, c_k4 - c_kt * (KTL / 4));
+    if (ksteps == KTL / 4)
+      mma_ktile<CONJB, PM, PN, G::A_PLANE, G::B_PLANE, KTL / 4, G::MAXT, true, true>(cre, cim, tm, tn, base, q, j, cnt, ksteps);
+    else
+      mma_ktile<CONJB, PM, PN, G::A_PLANE, G::B_PLANE, KTL / 4, G::MAXT, false, true>(cre, cim, tm, tn, base, q, j, cnt, ksteps);
+    if (c_kt == c_nk - 1) {
+#pragma unroll
+      for (int e = 0; e < G::MAXT; ++e) {
+        if (e < cnt) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const long long o = (long long)(m0 + tm[e] * TILE + q + 4 * r) * c_ldc + n0 + tn[e] * TILE + j;
+            cCre[o] = cre[e][r];
+            cCim[o] = cim[e][r];
+          }
+        }
+      }
+    }
+    if (++c_kt == c_nk) {
+      c_kt = 0;
+      if (++c_pm == c_npm) {
+        c_pm = 0;
+        if (++c_pn == c_npn) {
+          c_pn = 0;
+          if (++c_g < count) load_compute_desc(c_g);
+        }
+      }
+    }
+  };
+
+  QK_FETCH_SET(ra0, rb0);
+  if (total > 1) QK_FETCH_SET(ra1, rb1);
+  QK_STASH_SET(0, ra0, rb0);
+  qk_lds_barrier();
+  int s = 0;
+  while (s + 3 < total) {
+    QK_FETCH_SET(ra0, rb0);
+    compute_step(0);
+    QK_STASH_SET(1, ra1, rb1);
+    qk_lds_barrier();
+    QK_FETCH_SET(ra1, rb1);
+    compute_step(1);
+    QK_STASH_SET(0, ra0, rb0);
+    qk_lds_barrier();
+    s += 2;
+  }
+  for (; s < total; ++s) {
+    const bool even = (s & 1) == 0;
+    if (s + 2 < total) {
+      if (even) QK_FETCH_SET(ra0, rb0); else QK_FETCH_SET(ra1, rb1);
+    }
+    compute_step(s & 1);
+    if (s + 1 < total) {
+      if (even) QK_STASH_SET(1, ra1, rb1); else QK_STASH_SET(0, ra0, rb0);
+    }
+    qk_lds_barrier();
+  }
+#undef QK_FETCH_SET
+#undef QK_STASH_SET
+  __syncthreads();
+}
+
+template <int PN, int KTL, int OCC, int NW, int PMT>
+__global__ __launch_bounds__(64 * NW, OCC) void qk_sweep_group_kernel(const SweepArgs g) {
+  using G = GemmCfg<PN, KTL, NW, PMT>;
+  constexpr int T = 64 * NW;
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  long long* slot = reinterpret_cast<long long*>(lds + G::LDS_D);
+  const int n = g.n_sites, n1 = n + 1;
+  // LDS after the staging buffers: slot | descriptors | x meta | y meta (per group member)
+  GemmDesc* desc = reinterpret_cast<GemmDesc*>(slot + 2);
+  long long* m_xo = reinterpret_cast<long long*>(desc + 2 * GMAX + 1);
+  long long* m_yo = m_xo + n;            // [GMAX][n]
+  int* m_xd = reinterpret_cast<int*>(m_yo + GMAX * n);
+  int* m_xt = m_xd + n1;
+  int* m_yd = m_xt + n1;                 // [GMAX][n1]
+  int* m_yt = m_yd + GMAX * n1;          // [GMAX][n1]
+
+  double* Xre = g.scratch + (long long)blockIdx.x * 2 * (g.x_plane + g.t_plane);
+  double* Xim = Xre + g.x_plane;
+  double* Tre = Xim + g.x_plane;
+  double* Tim = Tre + g.t_plane;
+  const int tid = threadIdx.x;
+
+  for (;;) {
+    if (tid == 0) *slot = (long long)atomicAdd(g.counter, 1ull);
+    __syncthreads();
+    const long long gi = *slot;
+    __syncthreads();
+    if (gi >= g.ngroups) break;
+    const long long first = g.groups[2 * gi];
+    const int cnt = g.groups[2 * gi + 1];
+    const int xi = g.pairs[2 * first];
+    for (int e = tid; e < n1; e += T) {
+      m_xd[e] = g.xdims[(long long)xi * n1 + e];
+      m_xt[e] = g.xtrue[(long long)xi * n1 + e];
+      if (e < n) m_xo[e] = g.xoffs[(long long)xi * n + e];
+    }
+    for (int e = tid; e < cnt * n1; e += T) {
+      const int gg = e / n1, k = e - gg * n1;
+      const int yj = g.pairs[2 * (first + gg) + 1];
+      m_yd[gg * n1 + k] = g.ydims[(long long)yj * n1 + k];
+      m_yt[gg * n1 + k] = g.ytrue[(long long)yj * n1 + k];
+      if (k < n) m_yo[gg * n + k] = g.yoffs[(long long)yj * n + k];
+    }
+    __syncthreads();
+    // X_all at site 0: one 16x16 block per member, X[0][0] = 1
+    {
+      const int a = qk_uniform_i(m_xd[0]);
+      int rows = 0;
+      for (int gg = 0; gg < cnt; ++gg) rows += qk_uniform_i(m_yd[gg * n1]);
+      for (int e = tid; e < rows * a; e += T) {
+        const int r = e / a, c = e - r * a;
+        Xre[e] = (c == 0 && (r % TILE) == 0) ? 1.0 : 0.0;  // every member starts from a 1x1 bond padded to 16
+        Xim[e] = 0.0;
+      }
+      __syncthreads();
+    }
+    for (int k = 0; k < n; ++k) {
+      if (tid == 0) {
+        const int a = m_xd[k], a2 = m_xd[k + 1], at = m_xt[k];
+        int SB2 = 0;
+        for (int gg = 0; gg < cnt; ++gg) SB2 += m_yd[gg * n1 + k + 1];
+        int rowoff = 0, coff = 0;
+        for (int gg = 0; gg < cnt; ++gg) {
+          const int b = m_yd[gg * n1 + k], b2 = m_yd[gg * n1 + k + 1], bt = m_yt[gg * n1 + k];
+          for (int pp = 0; pp < 2; ++pp) {
+            GemmDesc& d = desc[2 * gg + pp];
+            d.Cre = Tre + (long long)pp * SB2 + coff;
+            d.c_plane = Tim - Tre;
+            d.ldc = 2 * SB2;
+            d.Are = Xre + (long long)rowoff * a;
+            d.a_plane = Xim - Xre;
+            d.lda = a;
+            d.Bre = g.ydata + m_yo[gg * n + k] + (long long)pp * b2;
+            d.b_plane = (long long)b * 2 * b2;
+            d.ldb = 2 * b2;
+            d.M = a, d.N = b2, d.Ktrue = bt;
+          }
+          rowoff += b, coff += b2;
+        }
+        GemmDesc& d = desc[2 * cnt];
+        d.Cre = Xre, d.c_plane = Xim - Xre, d.ldc = a2;
+        d.Are = Tre, d.a_plane = Tim - Tre, d.lda = SB2;
+        d.Bre = g.xdata + m_xo[k], d.b_plane = (long long)a * 2 * a2, d.ldb = a2;
+        d.M = SB2, d.N = a2, d.Ktrue = 2 * at;
+      }
+      __syncthreads();
+      zgemm_stream<false, PN, KTL, NW, PMT>(desc, 2 * cnt, lds);
+      zgemm_stream<true, PN, KTL, NW, PMT>(desc + 2 * cnt, 1, lds);
+    }
+    if (tid < cnt) {
+      // final environment of member `tid`: a 16x16 block at row offset sum of the earlier members' last bonds
+      int rowoff = 0;
+      for (int gg = 0; gg < tid; ++gg) rowoff += m_yd[gg * n1 + n];
+      const long long o = (long long)rowoff * m_xd[n];
+      const double re = Xre[o], im = Xim[o];
+      g.values[first + tid] = re * re + im * im;
+      if (g.z) {
+        g.z[2 * (first + tid)] = re;
+        g.z[2 * (first + tid) + 1] = im;
+      }
+    }
+    __syncthreads();
+  }
+}
+
 template <int PN, int KTL, bool PROF = false, int NW = 4, int PMT = 64>
 __global__ __launch_bounds__(64 * NW, 2) void qk_sweep_flat_kernel(const SweepArgs g) {
   using G = GemmCfg<PN, KTL, NW, PMT>;
@@ -1097,6 +1471,7 @@ extern "C" int qk_ctx_create(int device_id, qk_ctx** out) {
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(qk_sweep_deep_kernel<64, 16, 2, 4, 64>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(qk_sweep_deep_kernel<64, 16, 4, 8, 64>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(qk_sweep_deep_kernel<64, 16, 4, 8, 64, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(qk_sweep_group_kernel<64, 16, 4, 8, 64>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(qk_mma_bench_kernel<64, 16, 4, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)GemmCfg<64, 16, 4, 64>::LDS_B));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(qk_mma_bench_kernel<64, 16, 4, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)GemmCfg<64, 16, 4, 64>::LDS_B));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(qk_mma_bench_kernel<64, 16, 8, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)GemmCfg<64, 16, 4, 64>::LDS_B));
@@ -1226,9 +1601,15 @@ static int ensure_plan_uploaded(qk_ctx* c, qk_plan* p) {
     (void)hipFree(p->d_pairs);
     p->d_pairs = nullptr;
   }
+  if (p->d_groups) {
+    (void)hipFree(p->d_groups);
+    p->d_groups = nullptr;
+  }
   if (p->pairs.empty()) return QK_OK;
   HIP_TRY(hipMalloc(&p->d_pairs, p->pairs.size() * sizeof(int32_t)));
   HIP_TRY(hipMemcpy(p->d_pairs, p->pairs.data(), p->pairs.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+  HIP_TRY(hipMalloc(&p->d_groups, p->groups.size() * sizeof(int32_t)));
+  HIP_TRY(hipMemcpy(p->d_groups, p->groups.data(), p->groups.size() * sizeof(int32_t), hipMemcpyHostToDevice));
   p->up_ctx = c;
   return QK_OK;
 }
@@ -1250,9 +1631,12 @@ extern "C" int qk_gram_values(qk_ctx* c, const qk_mps_set* xs, const qk_mps_set*
   int rc = ensure_plan_uploaded(c, plan);
   if (rc != QK_OK) return rc;
 
-  const long long x_plane = (long long)xs->max_pad * ys->max_pad;
+  const bool grouped = (c->variant == 14);
+  const long long members = grouped ? GMAX : 1;  // pairs carried by one workgroup at a time
+  const long long x_plane = members * xs->max_pad * ys->max_pad;
   const long long t_plane = 2 * x_plane;
-  const int grid = (int)std::min<long long>(np, (long long)c->wgs_per_cu * c->num_cus);
+  const long long units = grouped ? (long long)plan->groups.size() / 2 : np;
+  const int grid = (int)std::min<long long>(units, (long long)c->wgs_per_cu * c->num_cus);
   const size_t need = (size_t)grid * 2 * (size_t)(x_plane + t_plane) * sizeof(double);
   if (need > c->scratch_bytes) {
     HIP_TRY(hipStreamSynchronize(c->stream));
@@ -1266,6 +1650,7 @@ extern "C" int qk_gram_values(qk_ctx* c, const qk_mps_set* xs, const qk_mps_set*
   a.ydata = ys->d_data, a.ydims = ys->d_dims, a.ytrue = ys->d_true, a.yoffs = ys->d_offs;
   a.n_sites = xs->n_sites;
   a.pairs = plan->d_pairs, a.npairs = np;
+  a.groups = plan->d_groups, a.ngroups = (long long)plan->groups.size() / 2;
   a.values = values_dev, a.z = z_dev;
   a.scratch = c->scratch, a.x_plane = x_plane, a.t_plane = t_plane;
   a.counter = c->counter;
@@ -1287,6 +1672,13 @@ extern "C" int qk_gram_values(qk_ctx* c, const qk_mps_set* xs, const qk_mps_set*
       HIP_TRY(hipMemsetAsync(c->prof, 0, 8 * sizeof(unsigned long long), c->stream));
       qk_sweep_flat_kernel<64, 16, true><<<dim3(grid), dim3(WG_THREADS), lds_b, c->stream>>>(a);
       break;
+    case 14: {  // group sweep: up to GMAX pairs sharing the x state per workgroup
+      const int ns = xs->n_sites;
+      const size_t lds_group = lds_b + 16 + (2 * GMAX + 1) * sizeof(GemmDesc) + (size_t)(1 + GMAX) * ns * sizeof(long long) + (size_t)(2 + 2 * GMAX) * (ns + 1) * sizeof(int);
+      if (lds_group > 80 * 1024) return fail(QK_EINVAL, "qk_gram_values: %d sites need %zu bytes of LDS per workgroup", ns, lds_group);
+      qk_sweep_group_kernel<64, 16, 4, 8, 64><<<dim3(grid), dim3(512), lds_group, c->stream>>>(a);
+      break;
+    }
     case 19:  // diagnostic: instrumented shipped kernel
       HIP_TRY(hipMemsetAsync(c->prof, 0, 8 * sizeof(unsigned long long), c->stream));
       qk_sweep_deep_kernel<64, 16, 4, 8, 64, true><<<dim3(grid), dim3(512), lds_deep, c->stream>>>(a);
