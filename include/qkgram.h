@@ -150,8 +150,8 @@ int qk_get_stats(qk_ctx* ctx, qk_stats* out);
  * out8 = {fetch issue, MFMA block, epilogue stores, stash (+vmcnt wait), barrier, phase prologue,
  *         phase-end barrier, wave lifetime}.  Never used by the timed kernels. */
 int qk_debug_profile(qk_ctx* ctx, unsigned long long* out8);
-/* Diagnostic: TFLOP/s of the bare MFMA block (LDS fragments -> MFMAs, no global traffic).
- * which: 0/1 = 4-wave workgroup with/without fragment pipelining, 2/3 = 8-wave workgroup. */
+/* Diagnostic: TFLOP/s of the MFMA block with the sweep's per-step ingredients added back one at a
+ * time.  which = 8*(8-wave workgroup) + {0 bare, 1 +barrier, 2 +stash, 3 +global fetch, 4 +deep fetch}. */
 int qk_debug_mma_bench(qk_ctx* ctx, int which, int wgs_per_cu, int reps, double* tflops);
 
 /* Device self-test of the f64 MFMA fragment maps the kernels rely on (returns

@@ -1382,11 +1382,13 @@ __global__ __launch_bounds__(64 * NW, 2) void qk_sweep_flat_kernel(const SweepAr
   }
 }
 
-// Diagnostic micro-kernel: the MFMA block alone (LDS fragments -> MFMAs), no global traffic and
-// no barriers inside the loop.  Measures how close mma_ktile gets to the matrix-pipe rate.
-template <int PN, int KTL, int NW, bool PIPE>
-__global__ __launch_bounds__(64 * NW, (NW == 8 ? 4 : 2)) void qk_mma_bench_kernel(int reps, double* out) {
-  using G = GemmCfg<PN, KTL, NW, 64>;
+// Diagnostic micro-kernel: the MFMA block alone (LDS fragments -> MFMAs), then with the other
+// per-step ingredients of the sweep added back one at a time (FLAGS bit 0: workgroup barrier per
+// step, bit 1: LDS stash of a staged tile, bit 2: global fetch of the next tile from an L2-resident
+// buffer, bit 3: two-step-deep fetch like zgemm_deep).  Measures what each ingredient costs.
+template <int NW, int FLAGS>
+__global__ __launch_bounds__(64 * NW, (NW == 8 ? 4 : 2)) void qk_mma_bench_kernel(int reps, const double* __restrict__ src, double* out) {
+  using G = GemmCfg<64, 16, NW, 64>;
   extern __shared__ __attribute__((aligned(16))) double lds[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1403,14 +1405,43 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 ? 4 : 2)) void qk_mma_bench_kerne
     tm[e] = t % 4;
     tn[e] = t / 4;
   }
-  for (int r = 0; r < reps; ++r)
-    mma_ktile<false, 64, PN, G::A_PLANE, G::B_PLANE, KTL / 4, G::MAXT, true, PIPE>(cre, cim, tm, tn, lds + (r & 1) * G::STAGE_D, q, j, G::MAXT, KTL / 4);
+  constexpr int U = G::UA + G::UB;  // 16-byte units per thread per plane pair
+  double2 r0[2 * U], r1[2 * U];
+#pragma unroll
+  for (int i = 0; i < 2 * U; ++i) r0[i] = r1[i] = make_double2(1e-3, 2e-3);
+  const double* base_src = src + (size_t)(blockIdx.x % 64) * 8192;  // 64 KiB window per workgroup, L2 resident
+  auto fetch = [&](double2 (&r)[2 * U], int step) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < 2 * U; ++i) r[i] = *reinterpret_cast<const double2*>(base_src + ((step & 3) * 2048 + (i * 64 * NW + tid) * 2) % 8192);
+  };
+  auto stash = [&](const double2 (&r)[2 * U], int buf) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < 2 * U; ++i) *reinterpret_cast<double2*>(lds + buf * G::STAGE_D + (i * 64 * NW + tid) * 2) = r[i];
+  };
+  if (FLAGS & 4) {
+    fetch(r0, 0);
+    if (FLAGS & 8) fetch(r1, 1);
+  }
+  for (int r = 0; r < reps; r += 2) {
+    // even step
+    if ((FLAGS & 4) && (FLAGS & 8)) fetch(r0, r + 2);
+    mma_ktile<false, 64, 64, G::A_PLANE, G::B_PLANE, 4, G::MAXT, true, true>(cre, cim, tm, tn, lds, q, j, G::MAXT, 4);
+    if (FLAGS & 2) stash((FLAGS & 8) ? r1 : r0, 1);
+    if ((FLAGS & 4) && !(FLAGS & 8)) fetch(r0, r + 1);
+    if (FLAGS & 1) qk_lds_barrier();
+    // odd step
+    if ((FLAGS & 4) && (FLAGS & 8)) fetch(r1, r + 3);
+    mma_ktile<false, 64, 64, G::A_PLANE, G::B_PLANE, 4, G::MAXT, true, true>(cre, cim, tm, tn, lds + G::STAGE_D, q, j, G::MAXT, 4);
+    if (FLAGS & 2) stash(r0, 0);
+    if ((FLAGS & 4) && !(FLAGS & 8)) fetch(r0, r + 2);
+    if (FLAGS & 1) qk_lds_barrier();
+  }
   double acc = 0;
 #pragma unroll
   for (int e = 0; e < G::MAXT; ++e)
 #pragma unroll
     for (int r = 0; r < 4; ++r) acc += cre[e][r] + cim[e][r];
-  out[(size_t)blockIdx.x * 64 * NW + tid] = acc;
+  out[(size_t)blockIdx.x * 64 * NW + tid] = acc + r0[0].x + r1[0].x;
 }
 
 __global__ void qk_scatter_kernel(const int32_t* __restrict__ pairs, const double* __restrict__ vals, long long n,
@@ -1472,10 +1503,16 @@ extern "C" int qk_ctx_create(int device_id, qk_ctx** out) {
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(qk_sweep_deep_kernel<64, 16, 4, 8, 64>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(qk_sweep_deep_kernel<64, 16, 4, 8, 64, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(qk_sweep_group_kernel<64, 16, 4, 8, 64>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
-  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(qk_mma_bench_kernel<64, 16, 4, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)GemmCfg<64, 16, 4, 64>::LDS_B));
-  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(qk_mma_bench_kernel<64, 16, 4, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)GemmCfg<64, 16, 4, 64>::LDS_B));
-  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(qk_mma_bench_kernel<64, 16, 8, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)GemmCfg<64, 16, 4, 64>::LDS_B));
-  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(qk_mma_bench_kernel<64, 16, 8, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)GemmCfg<64, 16, 4, 64>::LDS_B));
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(qk_mma_bench_kernel<4, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)GemmCfg<64, 16, 4, 64>::LDS_B));
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(qk_mma_bench_kernel<4, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)GemmCfg<64, 16, 4, 64>::LDS_B));
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(qk_mma_bench_kernel<4, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)GemmCfg<64, 16, 4, 64>::LDS_B));
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(qk_mma_bench_kernel<4, 7>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)GemmCfg<64, 16, 4, 64>::LDS_B));
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(qk_mma_bench_kernel<4, 15>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)GemmCfg<64, 16, 4, 64>::LDS_B));
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(qk_mma_bench_kernel<8, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)GemmCfg<64, 16, 4, 64>::LDS_B));
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(qk_mma_bench_kernel<8, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)GemmCfg<64, 16, 4, 64>::LDS_B));
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(qk_mma_bench_kernel<8, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)GemmCfg<64, 16, 4, 64>::LDS_B));
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(qk_mma_bench_kernel<8, 7>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)GemmCfg<64, 16, 4, 64>::LDS_B));
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(qk_mma_bench_kernel<8, 15>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)GemmCfg<64, 16, 4, 64>::LDS_B));
   if (const char* v = std::getenv("QK_VARIANT")) c->variant = std::atoi(v);
   if (const char* v = std::getenv("QK_WGS_PER_CU")) c->wgs_per_cu = std::max(1, std::min(2, std::atoi(v)));
   *out = c;
@@ -1815,33 +1852,46 @@ extern "C" int qk_debug_profile(qk_ctx* c, unsigned long long* out8) {
   return QK_OK;
 }
 
-// Diagnostic: TFLOP/s of the bare MFMA block. which: 0 = 4 waves PIPE, 1 = 4 waves no PIPE, 2 = 8 waves PIPE, 3 = 8 waves no PIPE
+// Diagnostic: TFLOP/s of the MFMA block with per-step ingredients added back (see qk_mma_bench_kernel).
+// which = 8 * (waves == 8) + flags-index, flags-index in {0: bare, 1: +barrier, 2: +barrier+stash, 3: +barrier+stash+fetch, 4: + deep fetch}
+template <int NW>
+static int run_mma_bench(qk_ctx* c, int fi, int grid, int reps, const double* src, double* out, size_t lds) {
+  switch (fi) {
+    case 0: qk_mma_bench_kernel<NW, 0><<<dim3(grid), dim3(64 * NW), lds, c->stream>>>(reps, src, out); break;
+    case 1: qk_mma_bench_kernel<NW, 1><<<dim3(grid), dim3(64 * NW), lds, c->stream>>>(reps, src, out); break;
+    case 2: qk_mma_bench_kernel<NW, 3><<<dim3(grid), dim3(64 * NW), lds, c->stream>>>(reps, src, out); break;
+    case 3: qk_mma_bench_kernel<NW, 7><<<dim3(grid), dim3(64 * NW), lds, c->stream>>>(reps, src, out); break;
+    default: qk_mma_bench_kernel<NW, 15><<<dim3(grid), dim3(64 * NW), lds, c->stream>>>(reps, src, out); break;
+  }
+  return 0;
+}
+
 extern "C" int qk_debug_mma_bench(qk_ctx* c, int which, int wgs_per_cu, int reps, double* tflops) {
   if (!c || !tflops) return fail(QK_EINVAL, "qk_debug_mma_bench: null argument");
   HIP_TRY(hipSetDevice(c->device));
-  const int nw = (which >= 2) ? 8 : 4;
+  const int nw = (which >= 8) ? 8 : 4;
+  const int fi = which & 7;
   const int grid = c->num_cus * wgs_per_cu;
-  double* out = nullptr;
+  double *out = nullptr, *src = nullptr;
   HIP_TRY(hipMalloc(&out, (size_t)grid * 64 * nw * sizeof(double)));
+  HIP_TRY(hipMalloc(&src, (size_t)64 * 8192 * sizeof(double) + 65536));
+  HIP_TRY(hipMemset(src, 0, (size_t)64 * 8192 * sizeof(double) + 65536));
   const size_t lds = GemmCfg<64, 16, 4, 64>::LDS_B;
   hipEvent_t e0, e1;
   HIP_TRY(hipEventCreate(&e0));
   HIP_TRY(hipEventCreate(&e1));
   for (int it = 0; it < 2; ++it) {
     HIP_TRY(hipEventRecord(e0, c->stream));
-    if (which == 0) qk_mma_bench_kernel<64, 16, 4, true><<<dim3(grid), dim3(256), lds, c->stream>>>(reps, out);
-    else if (which == 1) qk_mma_bench_kernel<64, 16, 4, false><<<dim3(grid), dim3(256), lds, c->stream>>>(reps, out);
-    else if (which == 2) qk_mma_bench_kernel<64, 16, 8, true><<<dim3(grid), dim3(512), lds, c->stream>>>(reps, out);
-    else qk_mma_bench_kernel<64, 16, 8, false><<<dim3(grid), dim3(512), lds, c->stream>>>(reps, out);
+    if (nw == 8) run_mma_bench<8>(c, fi, grid, reps, src, out, lds);
+    else run_mma_bench<4>(c, fi, grid, reps, src, out, lds);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(e1, c->stream));
     HIP_TRY(hipEventSynchronize(e1));
   }
   float ms = 0;
   HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
-  // per WG per rep: 16 tiles x 4 k-steps x 4 MFMAs x 2048 flop
-  *tflops = (double)grid * reps * 16.0 * 4 * 4 * 2048 / (ms * 1e-3) / 1e12;
-  (void)hipFree(out);
+  *tflops = (double)grid * reps * 16.0 * 4 * 4 * 2048 / (ms * 1e-3) / 1e12;  // 16 tiles x 4 k-steps x 4 MFMAs x 2048 flop per step
+  (void)hipFree(out), (void)hipFree(src);
   (void)hipEventDestroy(e0), (void)hipEventDestroy(e1);
   return QK_OK;
 }

@@ -2,8 +2,11 @@ import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from qml_cutensornet_amd import engine
 ctx = engine.Context(0)
-names = {0: "4 waves, pipelined frags", 1: "4 waves, plain", 2: "8 waves, pipelined frags", 3: "8 waves, plain"}
-for which in (0, 1, 2, 3):
-    for w in (1, 2):
-        tf = ctx.debug_mma_bench(which, w, 4000)
-        print(f"{names[which]:28s} wgs/cu {w}: {tf:6.2f} TFLOP/s  ({tf / 78.6432:.3f} of 78.6)")
+names = ["bare MFMA block", "+ barrier per step", "+ LDS stash", "+ global fetch (1 step ahead)", "+ global fetch (2 steps ahead)"]
+for nw in (4, 8):
+    for fi, nm in enumerate(names):
+        row = []
+        for w in (1, 2):
+            tf = ctx.debug_mma_bench(8 * (nw == 8) + fi, w, 4000)
+            row.append(f"{tf:6.2f} TF ({tf / 78.6432:.3f})")
+        print(f"{nw} waves  {nm:32s} wgs/cu 1: {row[0]}   wgs/cu 2: {row[1]}")
