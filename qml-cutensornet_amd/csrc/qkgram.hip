@@ -995,8 +995,8 @@ __global__ __launch_bounds__(64 * NW, OCC) void qk_sweep_deep_kernel(const Sweep
 // ----------------------------------------------------------------------------------------
 // v4: group sweep.  One workgroup carries up to GMAX pairs that share the x state through the
 // sweep in lockstep.  Per site:
-//   phase 1  = a STREAM of 2*cnt independent GEMMs  T_g,p[a x b'_g] = X_g^T B_g,p   (p = physical index)
-//              written into one stacked matrix T_all[(L,p)][sum_g b'_g];
+//   phase 1  = a STREAM of cnt independent GEMMs  T_g[a x 2b'_g] = X_g^T B_g, whose two column halves
+//              (physical index p) are written into one stacked matrix T_all[(L,p)][sum_g b'_g];
 //   phase 2  = ONE GEMM  X'_all[sum_g b'_g x a'] = T_all^T conj(A_k)  (A_k read once per group).
 // zgemm_stream runs the two-step-deep prefetch pipeline of zgemm_deep over a list of GEMM
 // descriptors without draining between them, so the fixed per-phase latencies (prologue, barriers,
@@ -1009,7 +1009,8 @@ struct GemmDesc {  // lives in LDS; planes: im = re + plane
   const double* Are;
   const double* Bre;
   long long c_plane, a_plane, b_plane;
-  int ldc, lda, ldb, M, N, Ktrue;
+  long long c_jump;  // output columns >= n_half land c_jump elements further (second physical index of T_all)
+  int ldc, lda, ldb, M, N, Ktrue, n_half, pad_;
 };
 
 __device__ __forceinline__ long long qk_uniform_ll(long long v) {
@@ -1119,12 +1120,15 @@ __device__ __forceinline__ void zgemm_stream(const GemmDesc* __restrict__ descs,
   // ---- compute-side iterator
   int c_g = 0, c_kt = 0, c_pm = 0, c_pn = 0;
   double *cCre, *cCim;
-  int c_ldc, c_M, c_N, c_nk, c_k4, c_npm, c_npn;
+  int c_ldc, c_M, c_N, c_nk, c_k4, c_npm, c_npn, c_nhalf;
+  long long c_jump;
   auto load_compute_desc = [&](int g) __attribute__((always_inline)) {
     const GemmDesc* d = descs + g;
     cCre = reinterpret_cast<double*>(qk_uniform_ll(reinterpret_cast<long long>(d->Cre)));
     cCim = cCre + qk_uniform_ll(d->c_plane);
     c_ldc = qk_uniform_i(d->ldc);
+    c_nhalf = qk_uniform_i(d->n_half);
+    c_jump = qk_uniform_ll(d->c_jump);
     c_M = qk_uniform_i(d->M), c_N = qk_uniform_i(d->N);
     const int K = qk_uniform_i(d->Ktrue);
     c_nk = (K + KTL - 1) / KTL, c_k4 = (K + 3) >> 2;
@@ -1163,7 +1167,8 @@ __device__ __forceinline__ void zgemm_stream(const GemmDesc* __restrict__ descs,
         if (e < cnt) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            const long long o = (long long)(m0 + tm[e] * TILE + q + 4 * r) * c_ldc + n0 + tn[e] * TILE + j;
+            const int col0 = n0 + tn[e] * TILE;  // tiles never straddle n_half (a multiple of 16)
+            const long long o = (long long)(m0 + tm[e] * TILE + q + 4 * r) * c_ldc + col0 + j + (col0 >= c_nhalf ? c_jump : 0);
             cCre[o] = cre[e][r];
             cCim[o] = cim[e][r];
           }
@@ -1223,7 +1228,7 @@ __global__ __launch_bounds__(64 * NW, OCC) void qk_sweep_group_kernel(const Swee
   const int n = g.n_sites, n1 = n + 1;
   // LDS after the staging buffers: slot | descriptors | x meta | y meta (per group member)
   GemmDesc* desc = reinterpret_cast<GemmDesc*>(slot + 2);
-  long long* m_xo = reinterpret_cast<long long*>(desc + 2 * GMAX + 1);
+  long long* m_xo = reinterpret_cast<long long*>(desc + GMAX + 1);
   long long* m_yo = m_xo + n;            // [GMAX][n]
   int* m_xd = reinterpret_cast<int*>(m_yo + GMAX * n);
   int* m_xt = m_xd + n1;
@@ -1278,30 +1283,33 @@ __global__ __launch_bounds__(64 * NW, OCC) void qk_sweep_group_kernel(const Swee
         int rowoff = 0, coff = 0;
         for (int gg = 0; gg < cnt; ++gg) {
           const int b = m_yd[gg * n1 + k], b2 = m_yd[gg * n1 + k + 1], bt = m_yt[gg * n1 + k];
-          for (int pp = 0; pp < 2; ++pp) {
-            GemmDesc& d = desc[2 * gg + pp];
-            d.Cre = Tre + (long long)pp * SB2 + coff;
+          {
+            GemmDesc& d = desc[gg];
+            d.Cre = Tre + coff;              // T_all[(L,p)][coff + r]: row (2L+p) of a [2a][SB2] matrix
             d.c_plane = Tim - Tre;
-            d.ldc = 2 * SB2;
+            d.ldc = 2 * SB2;                 // consecutive L are 2 rows of T_all apart
+            d.n_half = b2;                   // columns n >= b2 belong to p = 1 ...
+            d.c_jump = (long long)SB2 - b2;  // ... and start one T_all row further
             d.Are = Xre + (long long)rowoff * a;
             d.a_plane = Xim - Xre;
             d.lda = a;
-            d.Bre = g.ydata + m_yo[gg * n + k] + (long long)pp * b2;
+            d.Bre = g.ydata + m_yo[gg * n + k];
             d.b_plane = (long long)b * 2 * b2;
             d.ldb = 2 * b2;
-            d.M = a, d.N = b2, d.Ktrue = bt;
+            d.M = a, d.N = 2 * b2, d.Ktrue = bt;
           }
           rowoff += b, coff += b2;
         }
-        GemmDesc& d = desc[2 * cnt];
+        GemmDesc& d = desc[cnt];
+        d.n_half = a2, d.c_jump = 0;
         d.Cre = Xre, d.c_plane = Xim - Xre, d.ldc = a2;
         d.Are = Tre, d.a_plane = Tim - Tre, d.lda = SB2;
         d.Bre = g.xdata + m_xo[k], d.b_plane = (long long)a * 2 * a2, d.ldb = a2;
         d.M = SB2, d.N = a2, d.Ktrue = 2 * at;
       }
       __syncthreads();
-      zgemm_stream<false, PN, KTL, NW, PMT>(desc, 2 * cnt, lds);
-      zgemm_stream<true, PN, KTL, NW, PMT>(desc + 2 * cnt, 1, lds);
+      zgemm_stream<false, PN, KTL, NW, PMT>(desc, cnt, lds);
+      zgemm_stream<true, PN, KTL, NW, PMT>(desc + cnt, 1, lds);
     }
     if (tid < cnt) {
       // final environment of member `tid`: a 16x16 block at row offset sum of the earlier members' last bonds
@@ -1711,7 +1719,7 @@ extern "C" int qk_gram_values(qk_ctx* c, const qk_mps_set* xs, const qk_mps_set*
       break;
     case 14: {  // group sweep: up to GMAX pairs sharing the x state per workgroup
       const int ns = xs->n_sites;
-      const size_t lds_group = lds_b + 16 + (2 * GMAX + 1) * sizeof(GemmDesc) + (size_t)(1 + GMAX) * ns * sizeof(long long) + (size_t)(2 + 2 * GMAX) * (ns + 1) * sizeof(int);
+      const size_t lds_group = lds_b + 16 + (GMAX + 1) * sizeof(GemmDesc) + (size_t)(1 + GMAX) * ns * sizeof(long long) + (size_t)(2 + 2 * GMAX) * (ns + 1) * sizeof(int);
       if (lds_group > 80 * 1024) return fail(QK_EINVAL, "qk_gram_values: %d sites need %zu bytes of LDS per workgroup", ns, lds_group);
       qk_sweep_group_kernel<64, 16, 4, 8, 64><<<dim3(grid), dim3(512), lds_group, c->stream>>>(a);
       break;
