@@ -1417,10 +1417,14 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 ? 4 : 2)) void qk_mma_bench_kerne
   double2 r0[2 * U], r1[2 * U];
 #pragma unroll
   for (int i = 0; i < 2 * U; ++i) r0[i] = r1[i] = make_double2(1e-3, 2e-3);
-  const double* base_src = src + (size_t)(blockIdx.x % 64) * 8192;  // 64 KiB window per workgroup, L2 resident
+  // FLAGS bit 4: stream unique data from a large HBM-resident buffer (one 32 KiB tile per step and
+  // workgroup, wrapping inside a 256 MiB-per-64-workgroups region) instead of an L2-resident window
+  const bool big = (FLAGS & 16) != 0;
+  const double* base_src = big ? src + (size_t)(blockIdx.x % 512) * (size_t)(1 << 18) : src + (size_t)(blockIdx.x % 64) * 8192;
   auto fetch = [&](double2 (&r)[2 * U], int step) __attribute__((always_inline)) {
+    const size_t tile = big ? (size_t)(step & 63) * 4096 : (size_t)((step & 3) * 2048);
 #pragma unroll
-    for (int i = 0; i < 2 * U; ++i) r[i] = *reinterpret_cast<const double2*>(base_src + ((step & 3) * 2048 + (i * 64 * NW + tid) * 2) % 8192);
+    for (int i = 0; i < 2 * U; ++i) r[i] = *reinterpret_cast<const double2*>(base_src + tile + (size_t)((i * 64 * NW + tid) * 2) % (big ? 4096 : 8192));
   };
   auto stash = [&](const double2 (&r)[2 * U], int buf) __attribute__((always_inline)) {
 #pragma unroll
@@ -1516,11 +1520,15 @@ extern "C" int qk_ctx_create(int device_id, qk_ctx** out) {
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(qk_mma_bench_kernel<4, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)GemmCfg<64, 16, 4, 64>::LDS_B));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(qk_mma_bench_kernel<4, 7>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)GemmCfg<64, 16, 4, 64>::LDS_B));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(qk_mma_bench_kernel<4, 15>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)GemmCfg<64, 16, 4, 64>::LDS_B));
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(qk_mma_bench_kernel<4, 23>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)GemmCfg<64, 16, 4, 64>::LDS_B));
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(qk_mma_bench_kernel<4, 31>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)GemmCfg<64, 16, 4, 64>::LDS_B));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(qk_mma_bench_kernel<8, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)GemmCfg<64, 16, 4, 64>::LDS_B));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(qk_mma_bench_kernel<8, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)GemmCfg<64, 16, 4, 64>::LDS_B));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(qk_mma_bench_kernel<8, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)GemmCfg<64, 16, 4, 64>::LDS_B));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(qk_mma_bench_kernel<8, 7>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)GemmCfg<64, 16, 4, 64>::LDS_B));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(qk_mma_bench_kernel<8, 15>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)GemmCfg<64, 16, 4, 64>::LDS_B));
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(qk_mma_bench_kernel<8, 23>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)GemmCfg<64, 16, 4, 64>::LDS_B));
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(qk_mma_bench_kernel<8, 31>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)GemmCfg<64, 16, 4, 64>::LDS_B));
   if (const char* v = std::getenv("QK_VARIANT")) c->variant = std::atoi(v);
   if (const char* v = std::getenv("QK_WGS_PER_CU")) c->wgs_per_cu = std::max(1, std::min(2, std::atoi(v)));
   *out = c;
@@ -1869,7 +1877,9 @@ static int run_mma_bench(qk_ctx* c, int fi, int grid, int reps, const double* sr
     case 1: qk_mma_bench_kernel<NW, 1><<<dim3(grid), dim3(64 * NW), lds, c->stream>>>(reps, src, out); break;
     case 2: qk_mma_bench_kernel<NW, 3><<<dim3(grid), dim3(64 * NW), lds, c->stream>>>(reps, src, out); break;
     case 3: qk_mma_bench_kernel<NW, 7><<<dim3(grid), dim3(64 * NW), lds, c->stream>>>(reps, src, out); break;
-    default: qk_mma_bench_kernel<NW, 15><<<dim3(grid), dim3(64 * NW), lds, c->stream>>>(reps, src, out); break;
+    case 4: qk_mma_bench_kernel<NW, 15><<<dim3(grid), dim3(64 * NW), lds, c->stream>>>(reps, src, out); break;
+    case 5: qk_mma_bench_kernel<NW, 23><<<dim3(grid), dim3(64 * NW), lds, c->stream>>>(reps, src, out); break;
+    default: qk_mma_bench_kernel<NW, 31><<<dim3(grid), dim3(64 * NW), lds, c->stream>>>(reps, src, out); break;
   }
   return 0;
 }
@@ -1882,8 +1892,9 @@ extern "C" int qk_debug_mma_bench(qk_ctx* c, int which, int wgs_per_cu, int reps
   const int grid = c->num_cus * wgs_per_cu;
   double *out = nullptr, *src = nullptr;
   HIP_TRY(hipMalloc(&out, (size_t)grid * 64 * nw * sizeof(double)));
-  HIP_TRY(hipMalloc(&src, (size_t)64 * 8192 * sizeof(double) + 65536));
-  HIP_TRY(hipMemset(src, 0, (size_t)64 * 8192 * sizeof(double) + 65536));
+  const size_t src_bytes = (size_t)512 * (1 << 18) * sizeof(double) + 65536;  // 1 GiB: 2 MiB per workgroup slot
+  HIP_TRY(hipMalloc(&src, src_bytes));
+  HIP_TRY(hipMemset(src, 0, src_bytes));
   const size_t lds = GemmCfg<64, 16, 4, 64>::LDS_B;
   hipEvent_t e0, e1;
   HIP_TRY(hipEventCreate(&e0));

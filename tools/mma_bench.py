@@ -2,7 +2,7 @@ import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from qml_cutensornet_amd import engine
 ctx = engine.Context(0)
-names = ["bare MFMA block", "+ barrier per step", "+ LDS stash", "+ global fetch (1 step ahead)", "+ global fetch (2 steps ahead)"]
+names = ["bare MFMA block", "+ barrier per step", "+ LDS stash", "+ global fetch (1 step ahead)", "+ global fetch (2 steps ahead)", "  same, 1-ahead, from HBM stream", "  same, 2-ahead, from HBM stream"]
 for nw in (4, 8):
     for fi, nm in enumerate(names):
         row = []
