@@ -207,3 +207,26 @@ def test_ansatz_states_cfg3_slice(gpu_ctx):
     assert np.abs(K - vals.reshape(10, 10)).max() < TOL
     assert np.abs(Kt - K[:4, :]).max() < TOL
     assert np.abs(K[:3, :3] - R.gram_from_mps([m.tensors for m in states[:3]])).max() < TOL
+
+
+def test_driver_end_to_end(built, tmp_path, monkeypatch):
+    """N3: the main_no_test-shaped driver writes kernels/<stem>.npy and <stem>.json with the reference's names/keys."""
+    import json
+
+    from helpers import golden
+    from qml_cutensornet_amd import driver
+    from qml_cutensornet_amd.data import synthetic_features
+
+    monkeypatch.chdir(tmp_path)
+    K = driver.main(["GPU", "8", "1", "1.0", "1", "10", "10", "5", "nodata.csv"])
+    stem = "train_Nf8_r1_g1.0_p0.0_nn1_mslinear_Ntr10_s5_nodata"
+    saved = np.load(tmp_path / "kernels" / f"{stem}.npy")
+    prof = json.load(open(tmp_path / f"{stem}.json"))
+    assert saved.shape == (16, 16) and np.array_equal(saved, K)
+    assert prof["lenX"][0] == 16 and prof["n_procs"][0] == 1 and "kernel_mat_time" in prof
+    # same circuits as cfg1's golden fixture generator (8 q, 1 layer, d=1, gamma=1): compare on identical features
+    g = golden("cfg1_8q_r1_d1.npz")
+    from oracle import restatement as R
+
+    X = synthetic_features(16, 8, 5)
+    assert np.abs(K - R.gram_statevector(X, None, 1, 1.0, R.entanglement_graph(8, 1))).max() < 1e-10

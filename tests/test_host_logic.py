@@ -248,3 +248,16 @@ def test_assemble_gram_host():
     assert np.array_equal(K, np.array([[1, 0.4, 0.2], [0.4, 1, 0.3], [0.2, 0.3, 1]]))
     K2 = assemble_gram(2, 3, [np.array([[0, 0], [2, 1]])], [np.array([0.5, 0.25])], False)
     assert K2[0, 0] == 0.5 and K2[1, 2] == 0.25 and K2.sum() == 0.75
+
+
+def test_driver_names_and_argument_errors():
+    """File-name contract of the reference driver (main.py:161-162) and its argument check (main.py:79-80,123-124)."""
+    from qml_cutensornet_amd import driver
+
+    assert driver.run_name("train", 60, 6, 1.0, 2, 250, 5, "elliptic_preproc.csv") == "train_Nf60_r6_g1.0_p0.0_nn2_mslinear_Ntr250_s5_elliptic_preproc"
+    with pytest.raises(ValueError):
+        driver.main(["GPU", "8", "1"])
+    with pytest.raises(ValueError):
+        driver.main(["CPU", "8", "1", "1.0", "1", "10", "10", "5", "none.csv"])
+    x, src = driver.load_training_features("definitely_missing.csv", 10, 10, 5, 8)
+    assert src == "synthetic" and x.shape == (16, 8) and x.min() == 0.0 and abs(x.max() - 2.0) < 1e-12
