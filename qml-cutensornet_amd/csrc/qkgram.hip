@@ -308,6 +308,7 @@ struct SweepArgs {
   long long t_plane;  // doubles per T plane
   unsigned long long* counter;
   unsigned long long* prof;  // diagnostic build only: cycle sums per section (see QK_VARIANT=9)
+  int prio_mode;             // 0: none; 1: second half of the grid at s_setprio 1; 2: odd blocks at s_setprio 1
 };
 
 // C[M x N] = sum_k Aop[k][m] * Bop[k][n]   (complex, split planes; CONJB conjugates Bop)
@@ -922,6 +923,10 @@ __global__ __launch_bounds__(64 * NW, OCC) void qk_sweep_deep_kernel(const Sweep
   double* Tre = Xim + g.x_plane;
   double* Tim = Tre + g.t_plane;
   const int tid = threadIdx.x;
+  // Static priority for one of the two workgroups that share a CU: it wins the matrix pipe, finishes its
+  // MFMA phase first and does its fetch/stash/barrier while the other one computes (they alternate
+  // instead of falling into lock-step).  Which blocks share a CU is not defined; both guesses are offered.
+  if ((g.prio_mode == 1 && blockIdx.x >= gridDim.x / 2) || (g.prio_mode == 2 && (blockIdx.x & 1))) __builtin_amdgcn_s_setprio(1);
   long long pc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   const long long t_begin = PROF ? qk_stamp() : 0;
   for (;;) {
@@ -1708,6 +1713,8 @@ extern "C" int qk_gram_values(qk_ctx* c, const qk_mps_set* xs, const qk_mps_set*
   a.scratch = c->scratch, a.x_plane = x_plane, a.t_plane = t_plane;
   a.counter = c->counter;
   a.prof = c->prof;
+  a.prio_mode = 0;
+  if (const char* v = std::getenv("QK_PRIO")) a.prio_mode = std::atoi(v);
   HIP_TRY(hipMemsetAsync(c->counter, 0, sizeof(unsigned long long), c->stream));
   HIP_TRY(hipEventRecord(c->ev0, c->stream));
   constexpr size_t lds_b = GemmCfg<64, 16>::LDS_B;

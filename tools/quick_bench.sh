@@ -10,7 +10,7 @@ for vw in $1; do
 import json
 try:
     d = json.loads(open("gpurun_out/qb_${v}_${w}.json").read().strip().splitlines()[-1])
-    print("variant $v wgs/cu $w block $b: ms_per_step %.1f  kernel_ms %.1f  frac %.4f  entries/s %.0f diag_err %.1e" % (d["ms_per_step"], d["roofline"]["kernel_ms"], d["roofline"]["frac"], d["value"], d["config"]["diag_err"]))
+    print("variant $v wgs/cu $w block $b prio ${QK_PRIO:-0}: ms_per_step %.1f  kernel_ms %.1f  frac %.4f  entries/s %.0f diag_err %.1e" % (d["ms_per_step"], d["roofline"]["kernel_ms"], d["roofline"]["frac"], d["value"], d["config"]["diag_err"]))
 except Exception as e:
     print("variant $v wgs $w: bench failed", e)
 PY
