@@ -57,7 +57,11 @@ class GramJob:
         if self.world > 1:
             import torch.distributed as dist
 
-            dist.all_gather_into_tensor(self.all_vals, self.my_vals, group=self.group)
+            if dist.get_backend(self.group) == "nccl":  # RCCL over xGMI: the one collective of the path
+                dist.all_gather_into_tensor(self.all_vals, self.my_vals, group=self.group)
+            else:  # gloo (tests, several ranks on one GPU): same result through the list form
+                parts = list(self.all_vals.view(self.world, self.maxp).unbind(0))
+                dist.all_gather(parts, self.my_vals, group=self.group)
         self.ctx.scatter(self.all_pairs.data_ptr(), self.all_vals.data_ptr(), self.all_pairs.shape[0],
                          self.K.data_ptr(), self.nx, self.symmetric)
         return self.K
