@@ -171,11 +171,19 @@ def main():
     import torch
     import torch.distributed as dist
 
+    # rehearsal hooks (one-GPU box): QK_FORCE_DEVICE puts every rank on that GPU, QK_DIST_BACKEND=gloo
+    # replaces RCCL, which needs one GPU per rank.  The driver's multi-GPU runs use neither.
+    if "QK_FORCE_DEVICE" in os.environ:
+        local_rank = int(os.environ["QK_FORCE_DEVICE"])
+    backend = os.environ.get("QK_DIST_BACKEND", "nccl")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     def barrier():
         if world > 1:
@@ -255,7 +263,7 @@ def main():
                 "workload": f"{args.config}: {n} qubits x {reps} layers, d={d}, gamma={args.gamma}, truncation 1e-16, {npts}x{npts} symmetric training Gram",
                 "unique_pairs": int(job.plan.total_pairs),
                 "overlaps_per_s": job.plan.total_pairs / (ms_per_step * 1e-3),
-                "parallelism": f"pairs dealt round-robin to {world} rank(s); one RCCL all-gather of packed values",
+                "parallelism": f"pairs dealt round-robin to {world} rank(s); one {'RCCL' if backend == 'nccl' else backend} all-gather of packed values",
                 "max_bond_mean": float(chi_max.mean()),
                 "max_bond_max": int(chi_max.max()),
                 "mps_gib": info["device_bytes"] / 2**30,
