@@ -230,3 +230,71 @@ def test_driver_end_to_end(built, tmp_path, monkeypatch):
 
     X = synthetic_features(16, 8, 5)
     assert np.abs(K - R.gram_statevector(X, None, 1, 1.0, R.entanglement_graph(8, 1))).max() < 1e-10
+
+
+# ------------------------------------------------------------------ edge cases
+def test_edge_shapes(gpu_ctx):
+    """One-site chains, a 1x1 Gram, bonds straddling the 16-wide MFMA tile (15, 16, 17, 33), product states."""
+    import qml_cutensornet_amd as Q
+    from oracle import restatement as R
+
+    rng = np.random.default_rng(42)
+    # one site: the overlap is a plain 2-vector dot product
+    one = [Q.random_mps(1, [1, 1], rng) for _ in range(3)]
+    with gpu_ctx.upload(one) as d:
+        z = gpu_ctx.overlaps(d)
+    ref = np.array([[np.vdot(x.tensors[0].ravel(), y.tensors[0].ravel()) for x in one] for y in one])
+    assert np.abs(z - ref).max() < 1e-14
+    # single state
+    m = Q.random_mps(9, [1, 2, 4, 8, 15, 8, 4, 2, 1, 1], rng)
+    with gpu_ctx.upload([m]) as d:
+        K = gpu_ctx.gram(d)
+    assert K.shape == (1, 1) and abs(K[0, 0] - 1) < 1e-13
+    # tile-boundary bonds on both operands
+    profs = [[1, 2, 4, 8, 16, 17, 33, 17, 9, 5, 3, 2, 1], [1, 2, 4, 8, 15, 16, 32, 16, 8, 4, 2, 1, 1], [1, 2, 3, 5, 9, 17, 31, 16, 15, 8, 4, 2, 1], [1] * 13]
+    xs = [Q.random_mps(12, p, rng) for p in profs]
+    with gpu_ctx.upload(xs) as d:
+        z = gpu_ctx.overlaps(d)
+    ref = np.array([[R.mps_inner(x.tensors, y.tensors) for x in xs] for y in xs])
+    assert np.abs(z - ref).max() < TOL
+
+
+def test_host_layout_lrp(gpu_ctx):
+    """Site tensors handed over as [left][right][physical] (the order pytket-cutensornet is recalled to use)."""
+    import qml_cutensornet_amd as Q
+    from qml_cutensornet_amd import engine
+
+    rng = np.random.default_rng(8)
+    xs = [Q.random_mps(8, [1, 2, 4, 7, 9, 6, 3, 2, 1], rng) for _ in range(3)]
+
+    class Swapped:
+        def __init__(self, m):
+            self._m = m
+            self.tensors = [np.ascontiguousarray(t.transpose(0, 2, 1)) for t in m.tensors]
+
+        def bond_dims(self):
+            return self._m.bond_dims()
+
+        def __len__(self):
+            return len(self._m)
+
+    with gpu_ctx.upload(xs) as a, gpu_ctx.upload([Swapped(m) for m in xs], layout=engine.QK_LAYOUT_LRP) as b:
+        assert np.array_equal(gpu_ctx.gram(a), gpu_ctx.gram(b))
+
+
+def test_bad_inputs_fail_loudly(gpu_ctx):
+    import qml_cutensornet_amd as Q
+    from qml_cutensornet_amd import engine
+
+    rng = np.random.default_rng(1)
+    a = Q.random_mps(4, [1, 2, 2, 2, 1], rng)
+    b = Q.random_mps(5, [1, 2, 2, 2, 2, 1], rng)
+    with pytest.raises(engine.QkError):
+        gpu_ctx.upload([])
+    with pytest.raises(engine.QkError):
+        gpu_ctx.upload([a, b])  # different site counts in one set
+    with gpu_ctx.upload([a]) as da, gpu_ctx.upload([b]) as db:
+        with pytest.raises(engine.QkError, match="site counts"):
+            gpu_ctx.gram(da, db)
+    with pytest.raises(RuntimeError):
+        a.vdot(b)
