@@ -36,6 +36,7 @@ CONFIGS = {
     "cfg2": (20, 2, 1, 100),
     "cfg3": (40, 4, 2, 200),
     "cfg4": (60, 6, 2, 500),
+    "cfg5": (100, 10, 4, 1000),  # only tractable at small gamma (SURVEY.md addendum): pass --gamma 0.1
 }
 # fp64 matrix peak of MI355X: 256 CU x 4 SIMD x 32 flop/clk (v_mfma_f64_16x16x4: 2048 flop / 64 clk) x 2.4 GHz
 PEAK_F64_MFMA_TFLOPS = 256 * 4 * 32 * 2.4e9 / 1e12
@@ -138,12 +139,14 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--config", default="cfg4", choices=sorted(CONFIGS))
-    ap.add_argument("--gamma", type=float, default=1.0)
+    ap.add_argument("--gamma", type=float, default=None, help="default 1.0 (0.1 for cfg5, whose bonds explode at larger gamma)")
     ap.add_argument("--points", type=int, default=0, help="override the number of data points")
     ap.add_argument("--seed", type=int, default=5)
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU-baseline budget (0 = skip)")
     ap.add_argument("--workers", type=int, default=0, help="host processes for MPS building (0 = all cores / ranks)")
     args = ap.parse_args()
+    if args.gamma is None:
+        args.gamma = 0.1 if args.config == "cfg5" else 1.0
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
