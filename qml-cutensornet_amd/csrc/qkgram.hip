@@ -1400,7 +1400,7 @@ __global__ __launch_bounds__(64 * NW, 2) void qk_sweep_flat_kernel(const SweepAr
 // step, bit 1: LDS stash of a staged tile, bit 2: global fetch of the next tile from an L2-resident
 // buffer, bit 3: two-step-deep fetch like zgemm_deep).  Measures what each ingredient costs.
 template <int NW, int FLAGS>
-__global__ __launch_bounds__(64 * NW, (NW == 8 ? 4 : 2)) void qk_mma_bench_kernel(int reps, const double* __restrict__ src, double* out) {
+__global__ __launch_bounds__(64 * NW, (NW == 8 ? 4 : 2)) void qk_mma_bench_kernel(int reps, const double* __restrict__ src, double* out, double* cbuf, int epi_every) {
   using G = GemmCfg<64, 16, NW, 64>;
   extern __shared__ __attribute__((aligned(16))) double lds[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -1446,6 +1446,20 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 ? 4 : 2)) void qk_mma_bench_kerne
     if (FLAGS & 2) stash((FLAGS & 8) ? r1 : r0, 1);
     if ((FLAGS & 4) && !(FLAGS & 8)) fetch(r0, r + 1);
     if (FLAGS & 1) qk_lds_barrier();
+    if ((FLAGS & 32) && ((r / 2) % epi_every) == epi_every - 1) {  // FLAGS bit 5: the sweep's per-pass epilogue
+      double* cw = cbuf + (size_t)blockIdx.x * 2 * 64 * 64;       // one 64x64 complex block per workgroup
+#pragma unroll
+      for (int e = 0; e < G::MAXT; ++e) {
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+          const size_t o = (size_t)(tm[e] * TILE + q + 4 * rr) * 64 + tn[e] * TILE + j;
+          cw[o] = cre[e][rr];
+          cw[64 * 64 + o] = cim[e][rr];
+        }
+        cre[e] = (v4d){0, 0, 0, 0};
+        cim[e] = (v4d){0, 0, 0, 0};
+      }
+    }
     // odd step
     if ((FLAGS & 4) && (FLAGS & 8)) fetch(r1, r + 3);
     mma_ktile<false, 64, 64, G::A_PLANE, G::B_PLANE, 4, G::MAXT, true, true>(cre, cim, tm, tn, lds + G::STAGE_D, q, j, G::MAXT, 4);
@@ -1527,6 +1541,7 @@ extern "C" int qk_ctx_create(int device_id, qk_ctx** out) {
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(qk_mma_bench_kernel<4, 15>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)GemmCfg<64, 16, 4, 64>::LDS_B));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(qk_mma_bench_kernel<4, 23>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)GemmCfg<64, 16, 4, 64>::LDS_B));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(qk_mma_bench_kernel<4, 31>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)GemmCfg<64, 16, 4, 64>::LDS_B));
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(qk_mma_bench_kernel<4, 63>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)GemmCfg<64, 16, 4, 64>::LDS_B));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(qk_mma_bench_kernel<8, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)GemmCfg<64, 16, 4, 64>::LDS_B));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(qk_mma_bench_kernel<8, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)GemmCfg<64, 16, 4, 64>::LDS_B));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(qk_mma_bench_kernel<8, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)GemmCfg<64, 16, 4, 64>::LDS_B));
@@ -1534,6 +1549,7 @@ extern "C" int qk_ctx_create(int device_id, qk_ctx** out) {
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(qk_mma_bench_kernel<8, 15>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)GemmCfg<64, 16, 4, 64>::LDS_B));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(qk_mma_bench_kernel<8, 23>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)GemmCfg<64, 16, 4, 64>::LDS_B));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(qk_mma_bench_kernel<8, 31>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)GemmCfg<64, 16, 4, 64>::LDS_B));
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(qk_mma_bench_kernel<8, 63>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)GemmCfg<64, 16, 4, 64>::LDS_B));
   if (const char* v = std::getenv("QK_VARIANT")) c->variant = std::atoi(v);
   if (const char* v = std::getenv("QK_WGS_PER_CU")) c->wgs_per_cu = std::max(1, std::min(2, std::atoi(v)));
   *out = c;
@@ -1878,15 +1894,16 @@ extern "C" int qk_debug_profile(qk_ctx* c, unsigned long long* out8) {
 // Diagnostic: TFLOP/s of the MFMA block with per-step ingredients added back (see qk_mma_bench_kernel).
 // which = 8 * (waves == 8) + flags-index, flags-index in {0: bare, 1: +barrier, 2: +barrier+stash, 3: +barrier+stash+fetch, 4: + deep fetch}
 template <int NW>
-static int run_mma_bench(qk_ctx* c, int fi, int grid, int reps, const double* src, double* out, size_t lds) {
+static int run_mma_bench(qk_ctx* c, int fi, int grid, int reps, const double* src, double* out, size_t lds, double* cbuf, int epi) {
   switch (fi) {
-    case 0: qk_mma_bench_kernel<NW, 0><<<dim3(grid), dim3(64 * NW), lds, c->stream>>>(reps, src, out); break;
-    case 1: qk_mma_bench_kernel<NW, 1><<<dim3(grid), dim3(64 * NW), lds, c->stream>>>(reps, src, out); break;
-    case 2: qk_mma_bench_kernel<NW, 3><<<dim3(grid), dim3(64 * NW), lds, c->stream>>>(reps, src, out); break;
-    case 3: qk_mma_bench_kernel<NW, 7><<<dim3(grid), dim3(64 * NW), lds, c->stream>>>(reps, src, out); break;
-    case 4: qk_mma_bench_kernel<NW, 15><<<dim3(grid), dim3(64 * NW), lds, c->stream>>>(reps, src, out); break;
-    case 5: qk_mma_bench_kernel<NW, 23><<<dim3(grid), dim3(64 * NW), lds, c->stream>>>(reps, src, out); break;
-    default: qk_mma_bench_kernel<NW, 31><<<dim3(grid), dim3(64 * NW), lds, c->stream>>>(reps, src, out); break;
+    case 0: qk_mma_bench_kernel<NW, 0><<<dim3(grid), dim3(64 * NW), lds, c->stream>>>(reps, src, out, cbuf, epi); break;
+    case 1: qk_mma_bench_kernel<NW, 1><<<dim3(grid), dim3(64 * NW), lds, c->stream>>>(reps, src, out, cbuf, epi); break;
+    case 2: qk_mma_bench_kernel<NW, 3><<<dim3(grid), dim3(64 * NW), lds, c->stream>>>(reps, src, out, cbuf, epi); break;
+    case 3: qk_mma_bench_kernel<NW, 7><<<dim3(grid), dim3(64 * NW), lds, c->stream>>>(reps, src, out, cbuf, epi); break;
+    case 4: qk_mma_bench_kernel<NW, 15><<<dim3(grid), dim3(64 * NW), lds, c->stream>>>(reps, src, out, cbuf, epi); break;
+    case 5: qk_mma_bench_kernel<NW, 23><<<dim3(grid), dim3(64 * NW), lds, c->stream>>>(reps, src, out, cbuf, epi); break;
+    case 6: qk_mma_bench_kernel<NW, 31><<<dim3(grid), dim3(64 * NW), lds, c->stream>>>(reps, src, out, cbuf, epi); break;
+    default: qk_mma_bench_kernel<NW, 63><<<dim3(grid), dim3(64 * NW), lds, c->stream>>>(reps, src, out, cbuf, epi); break;
   }
   return 0;
 }
@@ -1894,22 +1911,25 @@ static int run_mma_bench(qk_ctx* c, int fi, int grid, int reps, const double* sr
 extern "C" int qk_debug_mma_bench(qk_ctx* c, int which, int wgs_per_cu, int reps, double* tflops) {
   if (!c || !tflops) return fail(QK_EINVAL, "qk_debug_mma_bench: null argument");
   HIP_TRY(hipSetDevice(c->device));
-  const int nw = (which >= 8) ? 8 : 4;
+  const int nw = (which & 8) ? 8 : 4;
   const int fi = which & 7;
+  const int epi = std::max(1, which >> 4);  // epilogue every `epi` step pairs (which = 16*epi + 8*(8 waves) + flags index)
   const int grid = c->num_cus * wgs_per_cu;
   double *out = nullptr, *src = nullptr;
   HIP_TRY(hipMalloc(&out, (size_t)grid * 64 * nw * sizeof(double)));
   const size_t src_bytes = (size_t)512 * (1 << 18) * sizeof(double) + 65536;  // 1 GiB: 2 MiB per workgroup slot
   HIP_TRY(hipMalloc(&src, src_bytes));
   HIP_TRY(hipMemset(src, 0, src_bytes));
+  double* cbuf = nullptr;
+  HIP_TRY(hipMalloc(&cbuf, (size_t)grid * 2 * 64 * 64 * sizeof(double)));
   const size_t lds = GemmCfg<64, 16, 4, 64>::LDS_B;
   hipEvent_t e0, e1;
   HIP_TRY(hipEventCreate(&e0));
   HIP_TRY(hipEventCreate(&e1));
   for (int it = 0; it < 2; ++it) {
     HIP_TRY(hipEventRecord(e0, c->stream));
-    if (nw == 8) run_mma_bench<8>(c, fi, grid, reps, src, out, lds);
-    else run_mma_bench<4>(c, fi, grid, reps, src, out, lds);
+    if (nw == 8) run_mma_bench<8>(c, fi, grid, reps, src, out, lds, cbuf, epi);
+    else run_mma_bench<4>(c, fi, grid, reps, src, out, lds, cbuf, epi);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(e1, c->stream));
     HIP_TRY(hipEventSynchronize(e1));
@@ -1917,7 +1937,7 @@ extern "C" int qk_debug_mma_bench(qk_ctx* c, int which, int wgs_per_cu, int reps
   float ms = 0;
   HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
   *tflops = (double)grid * reps * 16.0 * 4 * 4 * 2048 / (ms * 1e-3) / 1e12;  // 16 tiles x 4 k-steps x 4 MFMAs x 2048 flop per step
-  (void)hipFree(out), (void)hipFree(src);
+  (void)hipFree(out), (void)hipFree(src), (void)hipFree(cbuf);
   (void)hipEventDestroy(e0), (void)hipEventDestroy(e1);
   return QK_OK;
 }
