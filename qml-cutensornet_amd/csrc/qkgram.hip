@@ -750,7 +750,7 @@ template <bool CONJB, int PN, int KTL, int NW, int PMT, bool PROF = false>
 __device__ __forceinline__ void zgemm_deep(double* __restrict__ Cre, double* __restrict__ Cim, const int ldc,
                                            const double* __restrict__ Are, const double* __restrict__ Aim, const int lda,
                                            const double* __restrict__ Bre, const double* __restrict__ Bim, const int ldb,
-                                           const int M, const int N, const int Ktrue, double* __restrict__ lds, long long (&pc)[8]) {
+                                           const int M, const int N, const int Ktrue, double* __restrict__ lds, long long (&pc)[8], const int dbg = 0) {
   using G = GemmCfg<PN, KTL, NW, PMT>;
   constexpr int PM = G::PM;
   const int tid = threadIdx.x;
@@ -855,7 +855,7 @@ __device__ __forceinline__ void zgemm_deep(double* __restrict__ Cre, double* __r
       mma_ktile<CONJB, PM, PN, G::A_PLANE, G::B_PLANE, KTL / 4, G::MAXT, true, true>(cre, cim, tm, tn, base, q, j, cnt, ksteps);
     else
       mma_ktile<CONJB, PM, PN, G::A_PLANE, G::B_PLANE, KTL / 4, G::MAXT, false, true>(cre, cim, tm, tn, base, q, j, cnt, ksteps);
-    if (c_kt == nk - 1) {
+    if (c_kt == nk - 1 && !(dbg & 1)) {
 #pragma unroll
       for (int e = 0; e < G::MAXT; ++e) {
         if (e < cnt) {
@@ -977,8 +977,8 @@ __global__ __launch_bounds__(64 * NW, OCC) void qk_sweep_deep_kernel(const Sweep
       const double* Aim = Are + (long long)a * 2 * a2;
       const double* Bre = g.ydata + ldl(m_yo + k);
       const double* Bim = Bre + (long long)b * 2 * b2;
-      zgemm_deep<false, PN, KTL, NW, PMT, PROF>(Tre, Tim, 2 * b2, Xre, Xim, a, Bre, Bim, 2 * b2, a, 2 * b2, ldi(m_yt + k), lds, pc);
-      zgemm_deep<true, PN, KTL, NW, PMT, PROF>(Xre, Xim, a2, Tre, Tim, b2, Are, Aim, a2, b2, a2, 2 * ldi(m_xt + k), lds, pc);
+      zgemm_deep<false, PN, KTL, NW, PMT, PROF>(Tre, Tim, 2 * b2, Xre, Xim, a, Bre, Bim, 2 * b2, a, 2 * b2, ldi(m_yt + k), lds, pc, g.debug_flags);
+      zgemm_deep<true, PN, KTL, NW, PMT, PROF>(Xre, Xim, a2, Tre, Tim, b2, Are, Aim, a2, b2, a2, 2 * ldi(m_xt + k), lds, pc, g.debug_flags);
     }
     if (tid == 0) {
       const double re = Xre[0], im = Xim[0];
@@ -1729,6 +1729,8 @@ extern "C" int qk_gram_values(qk_ctx* c, const qk_mps_set* xs, const qk_mps_set*
   a.scratch = c->scratch, a.x_plane = x_plane, a.t_plane = t_plane;
   a.counter = c->counter;
   a.prof = c->prof;
+  a.debug_flags = 0;
+  if (const char* v = std::getenv("QK_DEBUG_FLAGS")) a.debug_flags = std::atoi(v);
   a.prio_mode = 0;
   if (const char* v = std::getenv("QK_PRIO")) a.prio_mode = std::atoi(v);
   HIP_TRY(hipMemsetAsync(c->counter, 0, sizeof(unsigned long long), c->stream));
