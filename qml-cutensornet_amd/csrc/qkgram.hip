@@ -308,6 +308,7 @@ struct SweepArgs {
   long long t_plane;  // doubles per T plane
   unsigned long long* counter;
   unsigned long long* prof;  // diagnostic build only: cycle sums per section (see QK_VARIANT=9)
+  int debug_flags;           // timing experiments only (QK_DEBUG_FLAGS): bit 0 = skip the GEMM epilogue stores (WRONG results)
   int prio_mode;             // 0: none; 1: second half of the grid at s_setprio 1; 2: odd blocks at s_setprio 1
 };
 
