@@ -308,7 +308,7 @@ struct SweepArgs {
   long long t_plane;  // doubles per T plane
   unsigned long long* counter;
   unsigned long long* prof;  // diagnostic build only: cycle sums per section (see QK_VARIANT=9)
-  int debug_flags;           // timing experiments only (QK_DEBUG_FLAGS): bit 0 = skip the GEMM epilogue stores (WRONG results)
+  int debug_flags;           // timing experiments only (QK_DEBUG_FLAGS): bit 0 = skip epilogue stores, bit 1 = skip steady-state fetch/stash, bit 2 = skip MFMAs, bit 3 = skip steady-state barriers (all give WRONG results)
   int prio_mode;             // 0: none; 1: second half of the grid at s_setprio 1; 2: odd blocks at s_setprio 1
 };
 
@@ -852,10 +852,12 @@ __device__ __forceinline__ void zgemm_deep(double* __restrict__ Cre, double* __r
     }
     const double* base = lds + buf * G::STAGE_D;
     const int ksteps = min(KTL / 4, k4 - c_kt * (KTL / 4));
-    if (ksteps == KTL / 4)
-      mma_ktile<CONJB, PM, PN, G::A_PLANE, G::B_PLANE, KTL / 4, G::MAXT, true, true>(cre, cim, tm, tn, base, q, j, cnt, ksteps);
-    else
-      mma_ktile<CONJB, PM, PN, G::A_PLANE, G::B_PLANE, KTL / 4, G::MAXT, false, true>(cre, cim, tm, tn, base, q, j, cnt, ksteps);
+    if (!(dbg & 4)) {
+      if (ksteps == KTL / 4)
+        mma_ktile<CONJB, PM, PN, G::A_PLANE, G::B_PLANE, KTL / 4, G::MAXT, true, true>(cre, cim, tm, tn, base, q, j, cnt, ksteps);
+      else
+        mma_ktile<CONJB, PM, PN, G::A_PLANE, G::B_PLANE, KTL / 4, G::MAXT, false, true>(cre, cim, tm, tn, base, q, j, cnt, ksteps);
+    }
     if (c_kt == nk - 1 && !(dbg & 1)) {
 #pragma unroll
       for (int e = 0; e < G::MAXT; ++e) {
@@ -884,14 +886,14 @@ __device__ __forceinline__ void zgemm_deep(double* __restrict__ Cre, double* __r
   });
   int s = 0;
   while (s + 3 < total) {  // tiles s+2 and s+3 exist: both fetches unconditional
-    QK_T(0, QK_FETCH_SET(ra0, rb0));     // tile s+2
+    if (!(dbg & 2)) QK_T(0, QK_FETCH_SET(ra0, rb0));     // tile s+2
     QK_T(1, compute_step(0));            // tile s     (s is even here)
-    QK_T(3, QK_STASH_SET(1, ra1, rb1));  // tile s+1, fetched two steps ago
-    QK_T(4, qk_lds_barrier());
-    QK_T(0, QK_FETCH_SET(ra1, rb1));     // tile s+3
+    if (!(dbg & 2)) QK_T(3, QK_STASH_SET(1, ra1, rb1));  // tile s+1, fetched two steps ago
+    if (!(dbg & 8)) QK_T(4, qk_lds_barrier());
+    if (!(dbg & 2)) QK_T(0, QK_FETCH_SET(ra1, rb1));     // tile s+3
     QK_T(1, compute_step(1));            // tile s+1
-    QK_T(3, QK_STASH_SET(0, ra0, rb0));  // tile s+2
-    QK_T(4, qk_lds_barrier());
+    if (!(dbg & 2)) QK_T(3, QK_STASH_SET(0, ra0, rb0));  // tile s+2
+    if (!(dbg & 8)) QK_T(4, qk_lds_barrier());
     s += 2;
   }
   for (; s < total; ++s) {  // tail (at most 3 steps); s keeps its parity convention
