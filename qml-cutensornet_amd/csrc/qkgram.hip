@@ -1029,7 +1029,7 @@ __device__ __forceinline__ long long qk_uniform_ll(long long v) {
 __device__ __forceinline__ int qk_uniform_i(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
 template <bool CONJB, int PN, int KTL, int NW, int PMT>
-__device__ __forceinline__ void zgemm_stream(const GemmDesc* __restrict__ descs, const int count, double* __restrict__ lds) {
+__device__ __forceinline__ void zgemm_stream(const GemmDesc* __restrict__ descs, const int count, double* __restrict__ lds, const int dbg = 0) {
   using G = GemmCfg<PN, KTL, NW, PMT>;
   constexpr int PM = G::PM;
   const int tid = threadIdx.x;
@@ -1165,11 +1165,13 @@ __device__ __forceinline__ void zgemm_stream(const GemmDesc* __restrict__ descs,
     }
     const double* base = lds + buf * G::STAGE_D;
     const int ksteps = min(KTL / 4, c_k4 - c_kt * (KTL / 4));
-    if (ksteps == KTL / 4)
-      mma_ktile<CONJB, PM, PN, G::A_PLANE, G::B_PLANE, KTL / 4, G::MAXT, true, true>(cre, cim, tm, tn, base, q, j, cnt, ksteps);
-    else
-      mma_ktile<CONJB, PM, PN, G::A_PLANE, G::B_PLANE, KTL / 4, G::MAXT, false, true>(cre, cim, tm, tn, base, q, j, cnt, ksteps);
-    if (c_kt == c_nk - 1) {
+    if (!(dbg & 4)) {
+      if (ksteps == KTL / 4)
+        mma_ktile<CONJB, PM, PN, G::A_PLANE, G::B_PLANE, KTL / 4, G::MAXT, true, true>(cre, cim, tm, tn, base, q, j, cnt, ksteps);
+      else
+        mma_ktile<CONJB, PM, PN, G::A_PLANE, G::B_PLANE, KTL / 4, G::MAXT, false, true>(cre, cim, tm, tn, base, q, j, cnt, ksteps);
+    }
+    if (c_kt == c_nk - 1 && !(dbg & 1)) {
 #pragma unroll
       for (int e = 0; e < G::MAXT; ++e) {
         if (e < cnt) {
@@ -1201,14 +1203,14 @@ __device__ __forceinline__ void zgemm_stream(const GemmDesc* __restrict__ descs,
   qk_lds_barrier();
   int s = 0;
   while (s + 3 < total) {
-    QK_FETCH_SET(ra0, rb0);
+    if (!(dbg & 2)) QK_FETCH_SET(ra0, rb0);
     compute_step(0);
-    QK_STASH_SET(1, ra1, rb1);
-    qk_lds_barrier();
-    QK_FETCH_SET(ra1, rb1);
+    if (!(dbg & 2)) QK_STASH_SET(1, ra1, rb1);
+    if (!(dbg & 8)) qk_lds_barrier();
+    if (!(dbg & 2)) QK_FETCH_SET(ra1, rb1);
     compute_step(1);
-    QK_STASH_SET(0, ra0, rb0);
-    qk_lds_barrier();
+    if (!(dbg & 2)) QK_STASH_SET(0, ra0, rb0);
+    if (!(dbg & 8)) qk_lds_barrier();
     s += 2;
   }
   for (; s < total; ++s) {
@@ -1316,8 +1318,8 @@ __global__ __launch_bounds__(64 * NW, OCC) void qk_sweep_group_kernel(const Swee
         d.M = SB2, d.N = a2, d.Ktrue = 2 * at;
       }
       __syncthreads();
-      zgemm_stream<false, PN, KTL, NW, PMT>(desc, cnt, lds);
-      zgemm_stream<true, PN, KTL, NW, PMT>(desc + cnt, 1, lds);
+      zgemm_stream<false, PN, KTL, NW, PMT>(desc, cnt, lds, g.debug_flags);
+      zgemm_stream<true, PN, KTL, NW, PMT>(desc + cnt, 1, lds, g.debug_flags);
     }
     if (tid < cnt) {
       // final environment of member `tid`: a 16x16 block at row offset sum of the earlier members' last bonds
