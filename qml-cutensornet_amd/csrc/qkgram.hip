@@ -1018,7 +1018,8 @@ struct GemmDesc {  // lives in LDS; planes: im = re + plane
   const double* Bre;
   long long c_plane, a_plane, b_plane;
   long long c_jump;  // output columns >= n_half land c_jump elements further (second physical index of T_all)
-  int ldc, lda, ldb, M, N, Ktrue, n_half, pad_;
+  int ldc, lda, ldb, M, N, Ktrue, n_half;
+  int conjb;  // conjugate the B operand (the x-state tensor in X' = T^T conj(A))
 };
 
 __device__ __forceinline__ long long qk_uniform_ll(long long v) {
@@ -1028,8 +1029,8 @@ __device__ __forceinline__ long long qk_uniform_ll(long long v) {
 }
 __device__ __forceinline__ int qk_uniform_i(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
-template <bool CONJB, int PN, int KTL, int NW, int PMT>
-__device__ __forceinline__ void zgemm_stream(const GemmDesc* __restrict__ descs, const int count, double* __restrict__ lds, const int dbg = 0) {
+template <int PN, int KTL, int NW, int PMT>
+__device__ __forceinline__ void zgemm_stream(const GemmDesc* __restrict__ descs, const int count, double* __restrict__ lds, const bool fence, const int dbg = 0) {
   using G = GemmCfg<PN, KTL, NW, PMT>;
   constexpr int PM = G::PM;
   const int tid = threadIdx.x;
@@ -1048,6 +1049,7 @@ __device__ __forceinline__ void zgemm_stream(const GemmDesc* __restrict__ descs,
   int f_g = 0, f_kt = 0, f_pm = 0, f_pn = 0;
   const double *fAre, *fAim, *fBre, *fBim;
   int f_lda, f_ldb, f_M, f_N, f_nk, f_npm, f_npn;
+  double f_sgn = 1.0, sgn0 = 1.0, sgn1 = 1.0;  // sign of the staged B imaginary plane (conjugation), per register set
   unsigned rowoffA[G::UA], rowoffB[G::UB];
   int colA[G::UA], colB[G::UB];
 #pragma unroll
@@ -1062,6 +1064,7 @@ __device__ __forceinline__ void zgemm_stream(const GemmDesc* __restrict__ descs,
     fBim = fBre + qk_uniform_ll(d->b_plane);
     f_lda = qk_uniform_i(d->lda), f_ldb = qk_uniform_i(d->ldb);
     f_M = qk_uniform_i(d->M), f_N = qk_uniform_i(d->N);
+    f_sgn = qk_uniform_i(d->conjb) ? -1.0 : 1.0;
     f_nk = (qk_uniform_i(d->Ktrue) + KTL - 1) / KTL;
     f_npm = (f_M + PM - 1) / PM, f_npn = (f_N + PN - 1) / PN;
 #pragma unroll
@@ -1077,10 +1080,11 @@ __device__ __forceinline__ void zgemm_stream(const GemmDesc* __restrict__ descs,
 #pragma unroll
   for (int i = 0; i < 2 * G::UB; ++i) rb0[i] = rb1[i] = make_double2(0.0, 0.0);
 
-#define QK_FETCH_SET(RA, RB)                                                      \
+#define QK_FETCH_SET(RA, RB, SG)                                                  \
   do {                                                                            \
     const int m0_ = f_pm * PM, n0_ = f_pn * PN;                                   \
     const int mcols_ = min(PM, f_M - m0_), ncols_ = min(PN, f_N - n0_);           \
+    SG = f_sgn;                                                                   \
     const long long ka_ = (long long)f_kt * KTL * f_lda + m0_;                    \
     const long long kb_ = (long long)f_kt * KTL * f_ldb + n0_;                    \
     const double* are_ = fAre + ka_;                                              \
@@ -1108,7 +1112,7 @@ __device__ __forceinline__ void zgemm_stream(const GemmDesc* __restrict__ descs,
       }                                                                           \
     }                                                                             \
   } while (0)
-#define QK_STASH_SET(BUF, RA, RB)                                                 \
+#define QK_STASH_SET(BUF, RA, RB, SG)                                             \
   do {                                                                            \
     double* base_ = lds + (BUF)*G::STAGE_D;                                       \
     _Pragma("unroll") for (int i = 0; i < G::UA; ++i) {                           \
@@ -1121,7 +1125,7 @@ __device__ __forceinline__ void zgemm_stream(const GemmDesc* __restrict__ descs,
       const int u = tid + G::WGT * i;                                             \
       const int o = (u / (PN / 2)) * PN + (u % (PN / 2)) * 2;                     \
       *reinterpret_cast<double2*>(base_ + 2 * G::A_PLANE + o) = RB[2 * i];        \
-      *reinterpret_cast<double2*>(base_ + 2 * G::A_PLANE + G::B_PLANE + o) = RB[2 * i + 1]; \
+      *reinterpret_cast<double2*>(base_ + 2 * G::A_PLANE + G::B_PLANE + o) = make_double2(SG * RB[2 * i + 1].x, SG * RB[2 * i + 1].y); \
     }                                                                             \
   } while (0)
 
@@ -1147,7 +1151,9 @@ __device__ __forceinline__ void zgemm_stream(const GemmDesc* __restrict__ descs,
   v4d cre[G::MAXT], cim[G::MAXT];
   int tm[G::MAXT], tn[G::MAXT];
   int cnt = 0;
+  bool crossed = false;  // the step just computed was the last one of its GEMM
   auto compute_step = [&](int buf) __attribute__((always_inline)) {
+    crossed = false;
     const int m0 = c_pm * PM, n0 = c_pn * PN;
     if (c_kt == 0) {
       const int mt = min(PM / TILE, (c_M - m0) / TILE);
@@ -1167,9 +1173,9 @@ __device__ __forceinline__ void zgemm_stream(const GemmDesc* __restrict__ descs,
     const int ksteps = min(KTL / 4, c_k4 - c_kt * (KTL / 4));
     if (!(dbg & 4)) {
       if (ksteps == KTL / 4)
-        mma_ktile<CONJB, PM, PN, G::A_PLANE, G::B_PLANE, KTL / 4, G::MAXT, true, true>(cre, cim, tm, tn, base, q, j, cnt, ksteps);
+        mma_ktile<false, PM, PN, G::A_PLANE, G::B_PLANE, KTL / 4, G::MAXT, true, true>(cre, cim, tm, tn, base, q, j, cnt, ksteps);
       else
-        mma_ktile<CONJB, PM, PN, G::A_PLANE, G::B_PLANE, KTL / 4, G::MAXT, false, true>(cre, cim, tm, tn, base, q, j, cnt, ksteps);
+        mma_ktile<false, PM, PN, G::A_PLANE, G::B_PLANE, KTL / 4, G::MAXT, false, true>(cre, cim, tm, tn, base, q, j, cnt, ksteps);
     }
     if (c_kt == c_nk - 1 && !(dbg & 1)) {
 #pragma unroll
@@ -1191,39 +1197,49 @@ __device__ __forceinline__ void zgemm_stream(const GemmDesc* __restrict__ descs,
         c_pm = 0;
         if (++c_pn == c_npn) {
           c_pn = 0;
+          crossed = true;
           if (++c_g < count) load_compute_desc(c_g);
         }
       }
     }
   };
 
-  QK_FETCH_SET(ra0, rb0);
-  if (total > 1) QK_FETCH_SET(ra1, rb1);
-  QK_STASH_SET(0, ra0, rb0);
+  // between GEMMs of an interleaved stream a full fence makes the finished GEMM's output visible
+  // to the whole workgroup (its consumer is the GEMM after the next one); inside a GEMM the cheap
+  // LDS-only barrier keeps the prefetch in flight
+#define QK_STEP_BARRIER()                          \
+  do {                                             \
+    if (fence && crossed) __syncthreads();         \
+    else qk_lds_barrier();                         \
+  } while (0)
+  QK_FETCH_SET(ra0, rb0, sgn0);
+  if (total > 1) QK_FETCH_SET(ra1, rb1, sgn1);
+  QK_STASH_SET(0, ra0, rb0, sgn0);
   qk_lds_barrier();
   int s = 0;
   while (s + 3 < total) {
-    if (!(dbg & 2)) QK_FETCH_SET(ra0, rb0);
+    if (!(dbg & 2)) QK_FETCH_SET(ra0, rb0, sgn0);
     compute_step(0);
-    if (!(dbg & 2)) QK_STASH_SET(1, ra1, rb1);
-    if (!(dbg & 8)) qk_lds_barrier();
-    if (!(dbg & 2)) QK_FETCH_SET(ra1, rb1);
+    if (!(dbg & 2)) QK_STASH_SET(1, ra1, rb1, sgn1);
+    if (!(dbg & 8)) QK_STEP_BARRIER();
+    if (!(dbg & 2)) QK_FETCH_SET(ra1, rb1, sgn1);
     compute_step(1);
-    if (!(dbg & 2)) QK_STASH_SET(0, ra0, rb0);
-    if (!(dbg & 8)) qk_lds_barrier();
+    if (!(dbg & 2)) QK_STASH_SET(0, ra0, rb0, sgn0);
+    if (!(dbg & 8)) QK_STEP_BARRIER();
     s += 2;
   }
   for (; s < total; ++s) {
     const bool even = (s & 1) == 0;
     if (s + 2 < total) {
-      if (even) QK_FETCH_SET(ra0, rb0); else QK_FETCH_SET(ra1, rb1);
+      if (even) QK_FETCH_SET(ra0, rb0, sgn0); else QK_FETCH_SET(ra1, rb1, sgn1);
     }
     compute_step(s & 1);
     if (s + 1 < total) {
-      if (even) QK_STASH_SET(1, ra1, rb1); else QK_STASH_SET(0, ra0, rb0);
+      if (even) QK_STASH_SET(1, ra1, rb1, sgn1); else QK_STASH_SET(0, ra0, rb0, sgn0);
     }
-    qk_lds_barrier();
+    QK_STEP_BARRIER();
   }
+#undef QK_STEP_BARRIER
 #undef QK_FETCH_SET
 #undef QK_STASH_SET
   __syncthreads();
@@ -1307,19 +1323,20 @@ __global__ __launch_bounds__(64 * NW, OCC) void qk_sweep_group_kernel(const Swee
             d.b_plane = (long long)b * 2 * b2;
             d.ldb = 2 * b2;
             d.M = a, d.N = 2 * b2, d.Ktrue = bt;
+            d.conjb = 0;
           }
           rowoff += b, coff += b2;
         }
         GemmDesc& d = desc[cnt];
-        d.n_half = a2, d.c_jump = 0;
+        d.n_half = a2, d.c_jump = 0, d.conjb = 1;
         d.Cre = Xre, d.c_plane = Xim - Xre, d.ldc = a2;
         d.Are = Tre, d.a_plane = Tim - Tre, d.lda = SB2;
         d.Bre = g.xdata + m_xo[k], d.b_plane = (long long)a * 2 * a2, d.ldb = a2;
         d.M = SB2, d.N = a2, d.Ktrue = 2 * at;
       }
       __syncthreads();
-      zgemm_stream<false, PN, KTL, NW, PMT>(desc, cnt, lds, g.debug_flags);
-      zgemm_stream<true, PN, KTL, NW, PMT>(desc + cnt, 1, lds, g.debug_flags);
+      zgemm_stream<PN, KTL, NW, PMT>(desc, cnt, lds, false, g.debug_flags);
+      zgemm_stream<PN, KTL, NW, PMT>(desc + cnt, 1, lds, false, g.debug_flags);
     }
     if (tid < cnt) {
       // final environment of member `tid`: a 16x16 block at row offset sum of the earlier members' last bonds
@@ -1331,6 +1348,112 @@ __global__ __launch_bounds__(64 * NW, OCC) void qk_sweep_group_kernel(const Swee
       if (g.z) {
         g.z[2 * (first + tid)] = re;
         g.z[2 * (first + tid) + 1] = im;
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// ----------------------------------------------------------------------------------------
+// v5: duo sweep.  One workgroup carries TWO independent pairs (chains A and B) through the sweep
+// and interleaves their phases in one GEMM stream  [A.p1, B.p1, A.p2, B.p2]  per site.  A phase's
+// consumer is the GEMM after the next one, so its store -> load round trip and the consumer's first
+// tile fetch are hidden behind the other chain's GEMM instead of stalling the workgroup (the
+// per-phase prologue + store drain measured ~6 us x 120 phases per pair on the single-chain kernel).
+// Sites where some GEMM has fewer than two steps (chain ends) fall back to one GEMM at a time.
+// ----------------------------------------------------------------------------------------
+template <int PN, int KTL, int OCC, int NW, int PMT>
+__global__ __launch_bounds__(64 * NW, OCC) void qk_sweep_duo_kernel(const SweepArgs g) {
+  using G = GemmCfg<PN, KTL, NW, PMT>;
+  constexpr int T = 64 * NW;
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  long long* slot = reinterpret_cast<long long*>(lds + G::LDS_D);
+  const int n = g.n_sites, n1 = n + 1;
+  GemmDesc* desc = reinterpret_cast<GemmDesc*>(slot + 2);            // [4]
+  int* flags = reinterpret_cast<int*>(desc + 4);                    // [2]: interleave ok, pad
+  long long* m_xo = reinterpret_cast<long long*>(flags + 2);        // [2][n]
+  long long* m_yo = m_xo + 2 * n;                                   // [2][n]
+  int* m_xd = reinterpret_cast<int*>(m_yo + 2 * n);                 // [2][n1] each below
+  int* m_yd = m_xd + 2 * n1;
+  int* m_xt = m_yd + 2 * n1;
+  int* m_yt = m_xt + 2 * n1;
+
+  const long long chain_stride = 2 * (g.x_plane + g.t_plane);
+  double* base = g.scratch + (long long)blockIdx.x * 2 * chain_stride;
+  const int tid = threadIdx.x;
+
+  for (;;) {
+    if (tid == 0) *slot = (long long)atomicAdd(g.counter, 1ull);
+    __syncthreads();
+    const long long gi = *slot;
+    __syncthreads();
+    const long long p0 = 2 * gi;
+    if (p0 >= g.npairs) break;
+    const int nch = (p0 + 1 < g.npairs) ? 2 : 1;
+    for (int e = tid; e < nch * n1; e += T) {
+      const int c = e / n1, k = e - c * n1;
+      const int xi = g.pairs[2 * (p0 + c)], yj = g.pairs[2 * (p0 + c) + 1];
+      m_xd[c * n1 + k] = g.xdims[(long long)xi * n1 + k];
+      m_yd[c * n1 + k] = g.ydims[(long long)yj * n1 + k];
+      m_xt[c * n1 + k] = g.xtrue[(long long)xi * n1 + k];
+      m_yt[c * n1 + k] = g.ytrue[(long long)yj * n1 + k];
+      if (k < n) {
+        m_xo[c * n + k] = g.xoffs[(long long)xi * n + k];
+        m_yo[c * n + k] = g.yoffs[(long long)yj * n + k];
+      }
+    }
+    __syncthreads();
+    for (int c = 0; c < nch; ++c) {
+      double* Xre = base + c * chain_stride;
+      double* Xim = Xre + g.x_plane;
+      const int ab = qk_uniform_i(m_xd[c * n1]) * qk_uniform_i(m_yd[c * n1]);
+      for (int e = tid; e < ab; e += T) {
+        Xre[e] = (e == 0) ? 1.0 : 0.0;
+        Xim[e] = 0.0;
+      }
+    }
+    __syncthreads();
+    for (int k = 0; k < n; ++k) {
+      if (tid < nch) {
+        const int c = tid;
+        double* Xre = base + c * chain_stride;
+        double* Xim = Xre + g.x_plane;
+        double* Tre = Xim + g.x_plane;
+        double* Tim = Tre + g.t_plane;
+        const int a = m_xd[c * n1 + k], a2 = m_xd[c * n1 + k + 1], b = m_yd[c * n1 + k], b2 = m_yd[c * n1 + k + 1];
+        GemmDesc& d1 = desc[c];          // phase 1: T[a x 2 b2] = X^T B
+        d1.Cre = Tre, d1.c_plane = Tim - Tre, d1.ldc = 2 * b2, d1.n_half = 2 * b2, d1.c_jump = 0;
+        d1.Are = Xre, d1.a_plane = Xim - Xre, d1.lda = a;
+        d1.Bre = g.ydata + m_yo[c * n + k], d1.b_plane = (long long)b * 2 * b2, d1.ldb = 2 * b2;
+        d1.M = a, d1.N = 2 * b2, d1.Ktrue = m_yt[c * n1 + k], d1.conjb = 0;
+        GemmDesc& d2 = desc[nch + c];    // phase 2: X'[b2 x a2] = T^T conj(A)
+        d2.Cre = Xre, d2.c_plane = Xim - Xre, d2.ldc = a2, d2.n_half = a2, d2.c_jump = 0;
+        d2.Are = Tre, d2.a_plane = Tim - Tre, d2.lda = b2;
+        d2.Bre = g.xdata + m_xo[c * n + k], d2.b_plane = (long long)a * 2 * a2, d2.ldb = a2;
+        d2.M = b2, d2.N = a2, d2.Ktrue = 2 * m_xt[c * n1 + k], d2.conjb = 1;
+      }
+      __syncthreads();
+      bool inter = (nch == 2);
+      if (inter) {  // every GEMM of the interleaved stream needs at least two steps (see zgemm_stream)
+        for (int i = 0; i < 4; ++i) {
+          const int M = qk_uniform_i(desc[i].M), N = qk_uniform_i(desc[i].N), K = qk_uniform_i(desc[i].Ktrue);
+          const int steps = ((M + G::PM - 1) / G::PM) * ((N + PN - 1) / PN) * ((K + KTL - 1) / KTL);
+          inter = inter && steps >= 2;
+        }
+      }
+      if (inter) {
+        zgemm_stream<PN, KTL, NW, PMT>(desc, 4, lds, true, g.debug_flags);
+      } else {
+        for (int i = 0; i < 2 * nch; ++i) zgemm_stream<PN, KTL, NW, PMT>(desc + i, 1, lds, false, g.debug_flags);
+      }
+    }
+    if (tid < nch) {
+      const double* Xre = base + tid * chain_stride;
+      const double re = Xre[0], im = Xre[g.x_plane];
+      g.values[p0 + tid] = re * re + im * im;
+      if (g.z) {
+        g.z[2 * (p0 + tid)] = re;
+        g.z[2 * (p0 + tid) + 1] = im;
       }
     }
     __syncthreads();
@@ -1539,6 +1662,7 @@ extern "C" int qk_ctx_create(int device_id, qk_ctx** out) {
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(qk_sweep_deep_kernel<64, 16, 4, 8, 64>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(qk_sweep_deep_kernel<64, 16, 4, 8, 64, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(qk_sweep_group_kernel<64, 16, 4, 8, 64>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(qk_sweep_duo_kernel<64, 16, 4, 8, 64>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(qk_mma_bench_kernel<4, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)GemmCfg<64, 16, 4, 64>::LDS_B));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(qk_mma_bench_kernel<4, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)GemmCfg<64, 16, 4, 64>::LDS_B));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(qk_mma_bench_kernel<4, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)GemmCfg<64, 16, 4, 64>::LDS_B));
@@ -1711,12 +1835,14 @@ extern "C" int qk_gram_values(qk_ctx* c, const qk_mps_set* xs, const qk_mps_set*
   if (rc != QK_OK) return rc;
 
   const bool grouped = (c->variant == 14);
-  const long long members = grouped ? GMAX : 1;  // pairs carried by one workgroup at a time
+  const bool duo = (c->variant == 16);
+  const long long members = grouped ? GMAX : 1;  // pairs stacked in one X/T buffer
+  const long long chains = duo ? 2 : 1;          // independent X/T buffer sets per workgroup
   const long long x_plane = members * xs->max_pad * ys->max_pad;
   const long long t_plane = 2 * x_plane;
-  const long long units = grouped ? (long long)plan->groups.size() / 2 : np;
+  const long long units = grouped ? (long long)plan->groups.size() / 2 : (duo ? (np + 1) / 2 : np);
   const int grid = (int)std::min<long long>(units, (long long)c->wgs_per_cu * c->num_cus);
-  const size_t need = (size_t)grid * 2 * (size_t)(x_plane + t_plane) * sizeof(double);
+  const size_t need = (size_t)grid * (size_t)chains * 2 * (size_t)(x_plane + t_plane) * sizeof(double);
   if (need > c->scratch_bytes) {
     HIP_TRY(hipStreamSynchronize(c->stream));
     if (c->scratch) HIP_TRY(hipFree(c->scratch));
@@ -1760,6 +1886,13 @@ extern "C" int qk_gram_values(qk_ctx* c, const qk_mps_set* xs, const qk_mps_set*
       const size_t lds_group = lds_b + 16 + (GMAX + 1) * sizeof(GemmDesc) + (size_t)(1 + GMAX) * ns * sizeof(long long) + (size_t)(2 + 2 * GMAX) * (ns + 1) * sizeof(int);
       if (lds_group > 80 * 1024) return fail(QK_EINVAL, "qk_gram_values: %d sites need %zu bytes of LDS per workgroup", ns, lds_group);
       qk_sweep_group_kernel<64, 16, 4, 8, 64><<<dim3(grid), dim3(512), lds_group, c->stream>>>(a);
+      break;
+    }
+    case 16: {  // duo sweep: two independent pairs per workgroup, phases interleaved in one stream
+      const int ns = xs->n_sites;
+      const size_t lds_duo = lds_b + 16 + 4 * sizeof(GemmDesc) + 8 + (size_t)4 * ns * sizeof(long long) + (size_t)8 * (ns + 1) * sizeof(int);
+      if (lds_duo > 80 * 1024) return fail(QK_EINVAL, "qk_gram_values: %d sites need %zu bytes of LDS per workgroup", ns, lds_duo);
+      qk_sweep_duo_kernel<64, 16, 4, 8, 64><<<dim3(grid), dim3(512), lds_duo, c->stream>>>(a);
       break;
     }
     case 19:  // diagnostic: instrumented shipped kernel
