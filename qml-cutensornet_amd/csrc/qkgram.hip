@@ -1049,7 +1049,8 @@ __device__ __forceinline__ void zgemm_stream(const GemmDesc* __restrict__ descs,
   int f_g = 0, f_kt = 0, f_pm = 0, f_pn = 0;
   const double *fAre, *fAim, *fBre, *fBim;
   int f_lda, f_ldb, f_M, f_N, f_nk, f_npm, f_npn;
-  double f_sgn = 1.0, sgn0 = 1.0, sgn1 = 1.0;  // sign of the staged B imaginary plane (conjugation), per register set
+  double f_sgn = 1.0, sgn0 = 1.0, sgn1 = 1.0;
+  bool f_new = false;  // the next fetch is the first tile of a GEMM other than the stream's first  // sign of the staged B imaginary plane (conjugation), per register set
   unsigned rowoffA[G::UA], rowoffB[G::UB];
   int colA[G::UA], colB[G::UB];
 #pragma unroll
@@ -1084,6 +1085,10 @@ __device__ __forceinline__ void zgemm_stream(const GemmDesc* __restrict__ descs,
   do {                                                                            \
     const int m0_ = f_pm * PM, n0_ = f_pn * PN;                                   \
     const int mcols_ = min(PM, f_M - m0_), ncols_ = min(PN, f_N - n0_);           \
+    if (fence && f_new) { /* the producer of this GEMM's input finished >= 1 GEMM ago: drain its stores now */ \
+      __syncthreads();                                                            \
+      f_new = false;                                                              \
+    }                                                                             \
     SG = f_sgn;                                                                   \
     const long long ka_ = (long long)f_kt * KTL * f_lda + m0_;                    \
     const long long kb_ = (long long)f_kt * KTL * f_ldb + n0_;                    \
@@ -1107,7 +1112,10 @@ __device__ __forceinline__ void zgemm_stream(const GemmDesc* __restrict__ descs,
         f_pm = 0;                                                                 \
         if (++f_pn == f_npn) {                                                    \
           f_pn = 0;                                                               \
-          if (++f_g < count) load_fetch_desc(f_g);                                \
+          if (++f_g < count) {                                                    \
+            load_fetch_desc(f_g);                                                 \
+            f_new = true;                                                         \
+          }                                                                       \
         }                                                                         \
       }                                                                           \
     }                                                                             \
@@ -1204,14 +1212,11 @@ __device__ __forceinline__ void zgemm_stream(const GemmDesc* __restrict__ descs,
     }
   };
 
-  // between GEMMs of an interleaved stream a full fence makes the finished GEMM's output visible
-  // to the whole workgroup (its consumer is the GEMM after the next one); inside a GEMM the cheap
-  // LDS-only barrier keeps the prefetch in flight
-#define QK_STEP_BARRIER()                          \
-  do {                                             \
-    if (fence && crossed) __syncthreads();         \
-    else qk_lds_barrier();                         \
-  } while (0)
+  // In an interleaved stream (fence = true) the consumer of a GEMM's output is the GEMM after the
+  // next one.  The full fence that makes that output visible is taken on the FETCH side, right
+  // before the consumer's first tile is requested -- by then the producer's stores have had a whole
+  // GEMM to drain -- and never right after the producer's epilogue.
+#define QK_STEP_BARRIER() qk_lds_barrier()
   QK_FETCH_SET(ra0, rb0, sgn0);
   if (total > 1) QK_FETCH_SET(ra1, rb1, sgn1);
   QK_STASH_SET(0, ra0, rb0, sgn0);
