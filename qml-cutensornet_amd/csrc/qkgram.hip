@@ -1001,6 +1001,293 @@ __global__ __launch_bounds__(64 * NW, OCC) void qk_sweep_deep_kernel(const Sweep
 }
 
 // ----------------------------------------------------------------------------------------
+// v6: lean steady state.  Same pipeline as zgemm_deep (flat step sequence, two-step-deep register
+// prefetch, raw LDS barrier), but everything that depends only on the pass is computed once per pass:
+// running operand pointers (+= one K-tile per step), clamped per-thread load offsets, LDS fragment
+// offsets of the wave's tiles and their output addresses.  A steady-state step is then 4 loads,
+// the MFMA block, 4 LDS stores, one barrier and a handful of scalar adds.  Written for the 8-wave,
+// 64x64, K-tile-16 configuration (one 16-byte staging unit per thread and operand plane).
+// ----------------------------------------------------------------------------------------
+template <bool CONJB, bool FULLK>
+__device__ __forceinline__ void mma_lean(v4d (&cre)[2], v4d (&cim)[2], const int (&la)[2], const int (&lb)[2],
+                                         const double* __restrict__ base, const int cnt, const int ksteps) {
+  constexpr int PMN = 64, APL = 16 * 64, BPL = 16 * 64;  // staged planes: A re | A im | B re | B im
+  if constexpr (FULLK) {
+    double far[2][2], fai[2][2], fbr[2][2], fbi[2][2];
+    auto load = [&](int g, int buf) __attribute__((always_inline)) {
+      const int e = g >> 1, k0 = (g & 1) * 2;
+      const double* pa = base + la[e] + 4 * k0 * PMN;
+      const double* pb = base + lb[e] + 4 * k0 * PMN;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        far[buf][h] = pa[h * 4 * PMN];
+        fai[buf][h] = pa[APL + h * 4 * PMN];
+        fbr[buf][h] = pb[h * 4 * PMN];
+        fbi[buf][h] = CONJB ? -pb[BPL + h * 4 * PMN] : pb[BPL + h * 4 * PMN];
+      }
+    };
+    if (cnt > 0) load(0, 0);
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int e = g >> 1;
+      if (e < cnt) {
+        if (g + 1 < 4 && ((g + 1) >> 1) < cnt) load(g + 1, (g + 1) & 1);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const double ar = far[g & 1][h], ai = fai[g & 1][h], br = fbr[g & 1][h], bi = fbi[g & 1][h];
+          cre[e] = __builtin_amdgcn_mfma_f64_16x16x4f64(ar, br, cre[e], 0, 0, 0);
+          cim[e] = __builtin_amdgcn_mfma_f64_16x16x4f64(ar, bi, cim[e], 0, 0, 0);
+          cre[e] = __builtin_amdgcn_mfma_f64_16x16x4f64(-ai, bi, cre[e], 0, 0, 0);
+          cim[e] = __builtin_amdgcn_mfma_f64_16x16x4f64(ai, br, cim[e], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+  } else {
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      if (e < cnt) {
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+          if (ks < ksteps) {
+            const double* pa = base + la[e] + 4 * ks * PMN;
+            const double* pb = base + lb[e] + 4 * ks * PMN;
+            const double ar = pa[0], ai = pa[APL], br = pb[0];
+            double bi = pb[BPL];
+            if (CONJB) bi = -bi;
+            cre[e] = __builtin_amdgcn_mfma_f64_16x16x4f64(ar, br, cre[e], 0, 0, 0);
+            cim[e] = __builtin_amdgcn_mfma_f64_16x16x4f64(ar, bi, cim[e], 0, 0, 0);
+            cre[e] = __builtin_amdgcn_mfma_f64_16x16x4f64(-ai, bi, cre[e], 0, 0, 0);
+            cim[e] = __builtin_amdgcn_mfma_f64_16x16x4f64(ai, br, cim[e], 0, 0, 0);
+          }
+        }
+      }
+    }
+  }
+}
+
+template <bool CONJB>
+__device__ __forceinline__ void zgemm_lean(double* __restrict__ Cre, double* __restrict__ Cim, const int ldc,
+                                           const double* __restrict__ Are, const double* __restrict__ Aim, const int lda,
+                                           const double* __restrict__ Bre, const double* __restrict__ Bim, const int ldb,
+                                           const int M, const int N, const int Ktrue, double* __restrict__ lds) {
+  constexpr int PM = 64, PN = 64, KTL = 16, NW = 8;
+  constexpr int APL = KTL * PM, STAGE_D = 4 * APL;  // doubles per plane / per buffer
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int j = lane & 15, q = lane >> 4;
+  const int npm = (M + PM - 1) / PM, npn = (N + PN - 1) / PN;
+  const int nk = (Ktrue + KTL - 1) / KTL;
+  const int ks_last = ((Ktrue + 3) >> 2) - (nk - 1) * (KTL / 4);  // k-steps of the last K-tile (1..4)
+  const int total = npm * npn * nk;
+  const long long sA = (long long)KTL * lda, sB = (long long)KTL * ldb;
+
+  // per-thread staging role: one 16-byte unit per plane; LDS position is simply 2*tid
+  const int srow = tid >> 5, scol = (tid & 31) * 2;
+  const unsigned rA = (unsigned)(srow * lda), rB = (unsigned)(srow * ldb);
+  double* st0 = lds + 2 * tid;             // buffer 0
+  double* st1 = st0 + STAGE_D;             // buffer 1
+
+  // ---- fetch-side pass state
+  int f_pm = 0, f_pn = 0, f_left = nk;
+  const double *fa_re = Are, *fa_im = Aim, *fb_re = Bre, *fb_im = Bim;
+  unsigned offA = rA + (unsigned)min(scol, min(PM, M) - 2), offB = rB + (unsigned)min(scol, min(PN, N) - 2);
+  auto fetch_next_pass = [&]() __attribute__((always_inline)) {
+    if (++f_pm == npm) f_pm = 0, ++f_pn;
+    const int m0 = f_pm * PM, n0 = f_pn * PN;
+    fa_re = Are + m0, fa_im = Aim + m0, fb_re = Bre + n0, fb_im = Bim + n0;
+    offA = rA + (unsigned)min(scol, min(PM, M - m0) - 2);
+    offB = rB + (unsigned)min(scol, min(PN, N - n0) - 2);
+    f_left = nk;
+  };
+  double2 a0r, a0i, b0r, b0i, a1r, a1i, b1r, b1i;  // two staging register sets
+  a0r = a0i = b0r = b0i = a1r = a1i = b1r = b1i = make_double2(0.0, 0.0);
+#define QK_LFETCH(AR, AI, BR, BI)                              \
+  do {                                                         \
+    AR = *reinterpret_cast<const double2*>(fa_re + offA);      \
+    AI = *reinterpret_cast<const double2*>(fa_im + offA);      \
+    BR = *reinterpret_cast<const double2*>(fb_re + offB);      \
+    BI = *reinterpret_cast<const double2*>(fb_im + offB);      \
+    fa_re += sA, fa_im += sA, fb_re += sB, fb_im += sB;        \
+    if (--f_left == 0) fetch_next_pass();                      \
+  } while (0)
+#define QK_LSTASH(ST, AR, AI, BR, BI)                          \
+  do {                                                         \
+    *reinterpret_cast<double2*>(ST) = AR;                      \
+    *reinterpret_cast<double2*>(ST + APL) = AI;                \
+    *reinterpret_cast<double2*>(ST + 2 * APL) = BR;            \
+    *reinterpret_cast<double2*>(ST + 3 * APL) = BI;            \
+  } while (0)
+
+  // ---- compute-side pass state
+  int c_pm = 0, c_pn = 0, c_left = nk, cnt = 0;
+  int la[2], lb[2];
+  long long co[2];
+  v4d cre[2], cim[2];
+  auto compute_pass_setup = [&]() __attribute__((always_inline)) {
+    const int m0 = c_pm * PM, n0 = c_pn * PN;
+    const int mt = min(PM / TILE, (M - m0) / TILE), nt = min(PN / TILE, (N - n0) / TILE);
+    const int vt = mt * nt;
+    cnt = (vt > wave) ? (vt - wave + NW - 1) / NW : 0;
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      const int t = min(wave + NW * e, vt - 1);
+      const int tm = t % mt, tn = t / mt;
+      la[e] = q * PM + tm * TILE + j;
+      lb[e] = 2 * APL + q * PN + tn * TILE + j;
+      co[e] = (long long)(m0 + tm * TILE + q) * ldc + n0 + tn * TILE + j;
+      cre[e] = (v4d){0, 0, 0, 0};
+      cim[e] = (v4d){0, 0, 0, 0};
+    }
+    c_left = nk;
+  };
+  compute_pass_setup();
+  const long long crow = 4ll * ldc;
+  auto step = [&](const double* base) __attribute__((always_inline)) {
+    if (c_left > 1 || ks_last == KTL / 4) {
+      mma_lean<CONJB, true>(cre, cim, la, lb, base, cnt, KTL / 4);
+    } else {
+      mma_lean<CONJB, false>(cre, cim, la, lb, base, cnt, ks_last);
+    }
+    if (--c_left == 0) {
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        if (e < cnt) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            Cre[co[e] + r * crow] = cre[e][r];
+            Cim[co[e] + r * crow] = cim[e][r];
+          }
+        }
+      }
+      if (++c_pm == npm) c_pm = 0, ++c_pn;
+      if (c_pn < npn) compute_pass_setup();
+    }
+  };
+
+  QK_LFETCH(a0r, a0i, b0r, b0i);
+  if (total > 1) QK_LFETCH(a1r, a1i, b1r, b1i);
+  QK_LSTASH(st0, a0r, a0i, b0r, b0i);
+  qk_lds_barrier();
+  int s = 0;
+  while (s + 3 < total) {
+    QK_LFETCH(a0r, a0i, b0r, b0i);        // tile s+2
+    step(lds);                            // tile s (buffer 0)
+    QK_LSTASH(st1, a1r, a1i, b1r, b1i);   // tile s+1
+    qk_lds_barrier();
+    QK_LFETCH(a1r, a1i, b1r, b1i);        // tile s+3
+    step(lds + STAGE_D);                  // tile s+1 (buffer 1)
+    QK_LSTASH(st0, a0r, a0i, b0r, b0i);   // tile s+2
+    qk_lds_barrier();
+    s += 2;
+  }
+  for (; s < total; ++s) {
+    const bool even = (s & 1) == 0;
+    if (s + 2 < total) {
+      if (even) QK_LFETCH(a0r, a0i, b0r, b0i); else QK_LFETCH(a1r, a1i, b1r, b1i);
+    }
+    step(even ? lds : lds + STAGE_D);
+    if (s + 1 < total) {
+      if (even) QK_LSTASH(st1, a1r, a1i, b1r, b1i); else QK_LSTASH(st0, a0r, a0i, b0r, b0i);
+    }
+    qk_lds_barrier();
+  }
+#undef QK_LFETCH
+#undef QK_LSTASH
+  __syncthreads();
+}
+
+// the deep kernel's pair loop around the lean GEMM
+template <int OCC>
+__global__ __launch_bounds__(512, OCC) void qk_sweep_lean_kernel(const SweepArgs g) {
+  using G = GemmCfg<64, 16, 8, 64>;
+  constexpr int NW = 8;
+  constexpr bool PROF = false;
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  long long* slot = reinterpret_cast<long long*>(lds + G::LDS_D);
+  double* Xre = g.scratch + (long long)blockIdx.x * 2 * (g.x_plane + g.t_plane);
+  double* Xim = Xre + g.x_plane;
+  double* Tre = Xim + g.x_plane;
+  double* Tim = Tre + g.t_plane;
+  const int tid = threadIdx.x;
+  // Static priority for one of the two workgroups that share a CU: it wins the matrix pipe, finishes its
+  // MFMA phase first and does its fetch/stash/barrier while the other one computes (they alternate
+  // instead of falling into lock-step).  Which blocks share a CU is not defined; both guesses are offered.
+  if ((g.prio_mode == 1 && blockIdx.x >= gridDim.x / 2) || (g.prio_mode == 2 && (blockIdx.x & 1))) __builtin_amdgcn_s_setprio(1);
+  long long pc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  const long long t_begin = PROF ? qk_stamp() : 0;
+  for (;;) {
+    if (tid == 0) *slot = (long long)atomicAdd(g.counter, 1ull);
+    __syncthreads();
+    const long long p = *slot;
+    __syncthreads();
+    if (p >= g.npairs) break;
+    const int xi = g.pairs[2 * p], yj = g.pairs[2 * p + 1];
+    // Stage the pair's per-site metadata in LDS once (one coalesced pass) instead of chasing it
+    // through global memory at every site: [xd | yd | xt | yt] (n+1 ints each) then [xo | yo] (n int64).
+    const int n1 = g.n_sites + 1;
+    int* m_xd = reinterpret_cast<int*>(slot + 2);
+    int* m_yd = m_xd + n1;
+    int* m_xt = m_yd + n1;
+    int* m_yt = m_xt + n1;
+    long long* m_xo = reinterpret_cast<long long*>(m_xd + 4 * n1 + (4 * n1 & 1));
+    long long* m_yo = m_xo + g.n_sites;
+    for (int e = tid; e < n1; e += 64 * NW) {
+      m_xd[e] = g.xdims[(long long)xi * n1 + e];
+      m_yd[e] = g.ydims[(long long)yj * n1 + e];
+      m_xt[e] = g.xtrue[(long long)xi * n1 + e];
+      m_yt[e] = g.ytrue[(long long)yj * n1 + e];
+      if (e < g.n_sites) {
+        m_xo[e] = g.xoffs[(long long)xi * g.n_sites + e];
+        m_yo[e] = g.yoffs[(long long)yj * g.n_sites + e];
+      }
+    }
+    __syncthreads();
+    auto ldi = [&](const int* q_) __attribute__((always_inline)) { return __builtin_amdgcn_readfirstlane(*q_); };
+    auto ldl = [&](const long long* q_) __attribute__((always_inline)) {
+      const long long v = *q_;
+      const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v);
+      const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)((unsigned long long)v >> 32));
+      return (long long)(((unsigned long long)hi << 32) | lo);
+    };
+    {
+      const int a = ldi(m_xd), b = ldi(m_yd);
+      for (int e = tid; e < a * b; e += 64 * NW) {
+        Xre[e] = (e == 0) ? 1.0 : 0.0;
+        Xim[e] = 0.0;
+      }
+      __syncthreads();
+    }
+    for (int k = 0; k < g.n_sites; ++k) {
+      const int a = ldi(m_xd + k), a2 = ldi(m_xd + k + 1), b = ldi(m_yd + k), b2 = ldi(m_yd + k + 1);
+      const double* Are = g.xdata + ldl(m_xo + k);
+      const double* Aim = Are + (long long)a * 2 * a2;
+      const double* Bre = g.ydata + ldl(m_yo + k);
+      const double* Bim = Bre + (long long)b * 2 * b2;
+      zgemm_lean<false>(Tre, Tim, 2 * b2, Xre, Xim, a, Bre, Bim, 2 * b2, a, 2 * b2, ldi(m_yt + k), lds);
+      zgemm_lean<true>(Xre, Xim, a2, Tre, Tim, b2, Are, Aim, a2, b2, a2, 2 * ldi(m_xt + k), lds);
+    }
+    if (tid == 0) {
+      const double re = Xre[0], im = Xim[0];
+      g.values[p] = re * re + im * im;
+      if (g.z) {
+        g.z[2 * p] = re;
+        g.z[2 * p + 1] = im;
+      }
+    }
+    __syncthreads();
+  }
+  if (PROF && g.prof && (tid & 63) == 0) {
+    pc[7] = qk_stamp() - t_begin;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) atomicAdd(g.prof + c, (unsigned long long)pc[c]);
+  }
+}
+
+
+// ----------------------------------------------------------------------------------------
 // v4: group sweep.  One workgroup carries up to GMAX pairs that share the x state through the
 // sweep in lockstep.  Per site:
 //   phase 1  = a STREAM of cnt independent GEMMs  T_g[a x 2b'_g] = X_g^T B_g, whose two column halves
@@ -1668,6 +1955,7 @@ extern "C" int qk_ctx_create(int device_id, qk_ctx** out) {
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(qk_sweep_deep_kernel<64, 16, 4, 8, 64, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(qk_sweep_group_kernel<64, 16, 4, 8, 64>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(qk_sweep_duo_kernel<64, 16, 4, 8, 64>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(qk_sweep_lean_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(qk_mma_bench_kernel<4, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)GemmCfg<64, 16, 4, 64>::LDS_B));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(qk_mma_bench_kernel<4, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)GemmCfg<64, 16, 4, 64>::LDS_B));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(qk_mma_bench_kernel<4, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)GemmCfg<64, 16, 4, 64>::LDS_B));
@@ -1900,6 +2188,9 @@ extern "C" int qk_gram_values(qk_ctx* c, const qk_mps_set* xs, const qk_mps_set*
       qk_sweep_duo_kernel<64, 16, 4, 8, 64><<<dim3(grid), dim3(512), lds_duo, c->stream>>>(a);
       break;
     }
+    case 17:  // lean steady-state step (8 waves, 64x64, K-tile 16)
+      qk_sweep_lean_kernel<4><<<dim3(grid), dim3(512), lds_deep, c->stream>>>(a);
+      break;
     case 19:  // diagnostic: instrumented shipped kernel
       HIP_TRY(hipMemsetAsync(c->prof, 0, 8 * sizeof(unsigned long long), c->stream));
       qk_sweep_deep_kernel<64, 16, 4, 8, 64, true><<<dim3(grid), dim3(512), lds_deep, c->stream>>>(a);
