@@ -743,14 +743,6 @@ __device__ __forceinline__ void zgemm_flat(double* __restrict__ Cre, double* __r
 // the steady-state loop is unrolled by two with unconditional fetches so that the compiler's
 // vmcnt bookkeeping stays exact (a conditional fetch would force vmcnt(0) at the stash).
 // ----------------------------------------------------------------------------------------
-// wave-uniform values read through a per-lane path (LDS), moved to scalar registers
-__device__ __forceinline__ long long qk_uniform_ll(long long v) {
-  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v);
-  const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)((unsigned long long)v >> 32));
-  return (long long)(((unsigned long long)hi << 32) | lo);
-}
-__device__ __forceinline__ int qk_uniform_i(int v) { return __builtin_amdgcn_readfirstlane(v); }
-
 // Workgroup barrier that publishes LDS writes only: it does NOT drain outstanding global loads
 // (a __syncthreads() would wait vmcnt(0) and cancel the prefetch that is meant to stay in flight).
 __device__ __forceinline__ void qk_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
@@ -1234,45 +1226,47 @@ __global__ __launch_bounds__(512, OCC) void qk_sweep_lean_kernel(const SweepArgs
     const int xi = g.pairs[2 * p], yj = g.pairs[2 * p + 1];
     // Stage the pair's per-site metadata in LDS once (one coalesced pass) instead of chasing it
     // through global memory at every site: [xd | yd | xt | yt] (n+1 ints each) then [xo | yo] (n int64).
-    // Stage the pair's per-site metadata in LDS once, as 16-byte records {padded bond, true bond, plane
-    // offset}: recx[k], recy[k] for k = 0..n (the offset of record n is unused).  A site then needs four
-    // wide LDS reads issued back to back instead of a dozen dependent ones.
     const int n1 = g.n_sites + 1;
-    struct SiteRec {
-      int pad, tru;
-      long long off;
-    };
-    SiteRec* recx = reinterpret_cast<SiteRec*>(slot + 2);
-    SiteRec* recy = recx + n1;
+    int* m_xd = reinterpret_cast<int*>(slot + 2);
+    int* m_yd = m_xd + n1;
+    int* m_xt = m_yd + n1;
+    int* m_yt = m_xt + n1;
+    long long* m_xo = reinterpret_cast<long long*>(m_xd + 4 * n1 + (4 * n1 & 1));
+    long long* m_yo = m_xo + g.n_sites;
     for (int e = tid; e < n1; e += 64 * NW) {
-      SiteRec rx, ry;
-      rx.pad = g.xdims[(long long)xi * n1 + e], rx.tru = g.xtrue[(long long)xi * n1 + e];
-      ry.pad = g.ydims[(long long)yj * n1 + e], ry.tru = g.ytrue[(long long)yj * n1 + e];
-      rx.off = (e < g.n_sites) ? g.xoffs[(long long)xi * g.n_sites + e] : 0;
-      ry.off = (e < g.n_sites) ? g.yoffs[(long long)yj * g.n_sites + e] : 0;
-      recx[e] = rx, recy[e] = ry;
+      m_xd[e] = g.xdims[(long long)xi * n1 + e];
+      m_yd[e] = g.ydims[(long long)yj * n1 + e];
+      m_xt[e] = g.xtrue[(long long)xi * n1 + e];
+      m_yt[e] = g.ytrue[(long long)yj * n1 + e];
+      if (e < g.n_sites) {
+        m_xo[e] = g.xoffs[(long long)xi * g.n_sites + e];
+        m_yo[e] = g.yoffs[(long long)yj * g.n_sites + e];
+      }
     }
     __syncthreads();
+    auto ldi = [&](const int* q_) __attribute__((always_inline)) { return __builtin_amdgcn_readfirstlane(*q_); };
+    auto ldl = [&](const long long* q_) __attribute__((always_inline)) {
+      const long long v = *q_;
+      const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v);
+      const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)((unsigned long long)v >> 32));
+      return (long long)(((unsigned long long)hi << 32) | lo);
+    };
     {
-      const int a = qk_uniform_i(recx[0].pad), b = qk_uniform_i(recy[0].pad);
+      const int a = ldi(m_xd), b = ldi(m_yd);
       for (int e = tid; e < a * b; e += 64 * NW) {
         Xre[e] = (e == 0) ? 1.0 : 0.0;
         Xim[e] = 0.0;
       }
       __syncthreads();
     }
-    SiteRec cx = recx[0], cy = recy[0];  // records of the current site (every lane reads the same address)
     for (int k = 0; k < g.n_sites; ++k) {
-      const SiteRec nx = recx[k + 1], ny = recy[k + 1];
-      const int a = qk_uniform_i(cx.pad), a2 = qk_uniform_i(nx.pad), b = qk_uniform_i(cy.pad), b2 = qk_uniform_i(ny.pad);
-      const int at = qk_uniform_i(cx.tru), bt = qk_uniform_i(cy.tru);
-      const double* Are = g.xdata + qk_uniform_ll(cx.off);
+      const int a = ldi(m_xd + k), a2 = ldi(m_xd + k + 1), b = ldi(m_yd + k), b2 = ldi(m_yd + k + 1);
+      const double* Are = g.xdata + ldl(m_xo + k);
       const double* Aim = Are + (long long)a * 2 * a2;
-      const double* Bre = g.ydata + qk_uniform_ll(cy.off);
+      const double* Bre = g.ydata + ldl(m_yo + k);
       const double* Bim = Bre + (long long)b * 2 * b2;
-      zgemm_lean<false>(Tre, Tim, 2 * b2, Xre, Xim, a, Bre, Bim, 2 * b2, a, 2 * b2, bt, lds);
-      zgemm_lean<true>(Xre, Xim, a2, Tre, Tim, b2, Are, Aim, a2, b2, a2, 2 * at, lds);
-      cx = nx, cy = ny;
+      zgemm_lean<false>(Tre, Tim, 2 * b2, Xre, Xim, a, Bre, Bim, 2 * b2, a, 2 * b2, ldi(m_yt + k), lds);
+      zgemm_lean<true>(Xre, Xim, a2, Tre, Tim, b2, Are, Aim, a2, b2, a2, 2 * ldi(m_xt + k), lds);
     }
     if (tid == 0) {
       const double re = Xre[0], im = Xim[0];
@@ -1314,6 +1308,12 @@ struct GemmDesc {  // lives in LDS; planes: im = re + plane
   int conjb;  // conjugate the B operand (the x-state tensor in X' = T^T conj(A))
 };
 
+__device__ __forceinline__ long long qk_uniform_ll(long long v) {
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v);
+  const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)((unsigned long long)v >> 32));
+  return (long long)(((unsigned long long)hi << 32) | lo);
+}
+__device__ __forceinline__ int qk_uniform_i(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
 template <int PN, int KTL, int NW, int PMT>
 __device__ __forceinline__ void zgemm_stream(const GemmDesc* __restrict__ descs, const int count, double* __restrict__ lds, const bool fence, const int dbg = 0) {
