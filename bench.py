@@ -276,7 +276,7 @@ def main():
             },
             "roofline": {
                 "bound": "mfma",
-                "kernel": "qk_sweep_deep_kernel<64,16,4,8,64>",
+                "kernel": "qk_sweep_lean_kernel<4>",
                 "achieved": achieved,
                 "peak": PEAK_F64_MFMA_TFLOPS,
                 "unit": "TFLOP/s",

@@ -65,7 +65,7 @@ struct qk_ctx {
   size_t scratch_bytes = 0;
   unsigned long long* counter = nullptr;
   unsigned long long* prof = nullptr;  // 8 cycle sums of the diagnostic variant
-  int variant = 13;    // sweep kernel variant (QK_VARIANT): 13 = shipped (deep prefetch, 8 waves); 0, 2, 12 = earlier kernels kept for A/B; 9 = instrumented
+  int variant = 17;    // sweep kernel variant (QK_VARIANT): 17 = shipped (lean deep-prefetch sweep, 8 waves); 0, 2, 12, 13, 14, 16, 18 = other kernels kept for A/B; 9, 19 = instrumented
   int wgs_per_cu = 2;  // resident workgroups per CU (QK_WGS_PER_CU)
   qk_stats last{};
 };
@@ -2476,9 +2476,6 @@ extern "C" int qk_gram_values(qk_ctx* c, const qk_mps_set* xs, const qk_mps_set*
       else qk_sweep_duo_kernel<64, 16, 4, 8, 64><<<dim3(grid), dim3(512), lds_duo, c->stream>>>(a);
       break;
     }
-    case 17:  // lean steady-state step (8 waves, 64x64, K-tile 16)
-      qk_sweep_lean_kernel<4><<<dim3(grid), dim3(512), lds_deep, c->stream>>>(a);
-      break;
     case 19:  // diagnostic: instrumented shipped kernel
       HIP_TRY(hipMemsetAsync(c->prof, 0, 8 * sizeof(unsigned long long), c->stream));
       qk_sweep_deep_kernel<64, 16, 4, 8, 64, true><<<dim3(grid), dim3(512), lds_deep, c->stream>>>(a);
@@ -2486,8 +2483,11 @@ extern "C" int qk_gram_values(qk_ctx* c, const qk_mps_set* xs, const qk_mps_set*
     case 12:  // two-step-deep prefetch, 4 waves
       qk_sweep_deep_kernel<64, 16, 2, 4, 64><<<dim3(grid), dim3(256), lds_deep, c->stream>>>(a);
       break;
-    default:  // 13: two-step-deep prefetch, 8 waves (2 tiles per wave, 16 waves per CU) -- the shipped kernel
+    case 13:  // two-step-deep prefetch, 8 waves (2 tiles per wave, 16 waves per CU)
       qk_sweep_deep_kernel<64, 16, 4, 8, 64><<<dim3(grid), dim3(512), lds_deep, c->stream>>>(a);
+      break;
+    default:  // 17: the shipped kernel -- same pipeline with the lean steady-state step
+      qk_sweep_lean_kernel<4><<<dim3(grid), dim3(512), lds_deep, c->stream>>>(a);
       break;
   }
   HIP_TRY(hipGetLastError());
