@@ -1008,14 +1008,6 @@ __global__ __launch_bounds__(64 * NW, OCC) void qk_sweep_deep_kernel(const Sweep
 // the MFMA block, 4 LDS stores, one barrier and a handful of scalar adds.  Written for the 8-wave,
 // 64x64, K-tile-16 configuration (one 16-byte staging unit per thread and operand plane).
 // ----------------------------------------------------------------------------------------
-// value held by the neighbouring lane (lane ^ 1) -- DPP quad_perm [1,0,3,2], no LDS traffic
-__device__ __forceinline__ double qk_swap_neighbour(double x) {
-  const long long b = __builtin_bit_cast(long long, x);
-  const int lo = __builtin_amdgcn_mov_dpp((int)(b & 0xffffffffll), 0xB1, 0xF, 0xF, true);
-  const int hi = __builtin_amdgcn_mov_dpp((int)(b >> 32), 0xB1, 0xF, 0xF, true);
-  return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
-}
-
 template <bool CONJB, bool FULLK>
 __device__ __forceinline__ void mma_lean(v4d (&cre)[2], v4d (&cim)[2], const int (&la)[2], const int (&lb)[2],
                                          const double* __restrict__ base, const int cnt, const int ksteps) {
@@ -1144,8 +1136,7 @@ __device__ __forceinline__ void zgemm_lean(double* __restrict__ Cre, double* __r
       const int tm = t % mt, tn = t / mt;
       la[e] = q * PM + tm * TILE + j;
       lb[e] = 2 * APL + q * PN + tn * TILE + j;
-      // 16-byte stores: even lanes write rows q, q+4 at columns (j, j+1); odd lanes rows q+8, q+12 at (j-1, j)
-      co[e] = (long long)(m0 + tm * TILE + q + (j & 1) * 8) * ldc + n0 + tn * TILE + (j & ~1);
+      co[e] = (long long)(m0 + tm * TILE + q) * ldc + n0 + tn * TILE + j;
       cre[e] = (v4d){0, 0, 0, 0};
       cim[e] = (v4d){0, 0, 0, 0};
     }
@@ -1163,18 +1154,10 @@ __device__ __forceinline__ void zgemm_lean(double* __restrict__ Cre, double* __r
 #pragma unroll
       for (int e = 0; e < 2; ++e) {
         if (e < cnt) {
-          const bool odd = (j & 1) != 0;
-          {  // exchange with the neighbouring lane so that every lane owns two adjacent columns of two rows
-            const double s0 = odd ? cre[e][0] : cre[e][2], s1 = odd ? cre[e][1] : cre[e][3];
-            const double r0 = qk_swap_neighbour(s0), r1 = qk_swap_neighbour(s1);
-            *reinterpret_cast<double2*>(Cre + co[e]) = odd ? make_double2(r0, cre[e][2]) : make_double2(cre[e][0], r0);
-            *reinterpret_cast<double2*>(Cre + co[e] + crow) = odd ? make_double2(r1, cre[e][3]) : make_double2(cre[e][1], r1);
-          }
-          {
-            const double s0 = odd ? cim[e][0] : cim[e][2], s1 = odd ? cim[e][1] : cim[e][3];
-            const double r0 = qk_swap_neighbour(s0), r1 = qk_swap_neighbour(s1);
-            *reinterpret_cast<double2*>(Cim + co[e]) = odd ? make_double2(r0, cim[e][2]) : make_double2(cim[e][0], r0);
-            *reinterpret_cast<double2*>(Cim + co[e] + crow) = odd ? make_double2(r1, cim[e][3]) : make_double2(cim[e][1], r1);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            Cre[co[e] + r * crow] = cre[e][r];
+            Cim[co[e] + r * crow] = cim[e][r];
           }
         }
       }
