@@ -65,7 +65,7 @@ struct qk_ctx {
   size_t scratch_bytes = 0;
   unsigned long long* counter = nullptr;
   unsigned long long* prof = nullptr;  // 8 cycle sums of the diagnostic variant
-  int variant = 17;    // sweep kernel variant (QK_VARIANT): 17 = shipped (lean deep-prefetch sweep, 8 waves); 0, 2, 12, 13, 14, 16, 18 = other kernels kept for A/B; 9, 19 = instrumented
+  int variant = 17;    // sweep kernel variant (QK_VARIANT): 17 = shipped (lean deep-prefetch sweep, 8 waves); 0, 2, 12, 13, 14, 16 = other kernels kept for A/B; 9, 19 = instrumented
   int wgs_per_cu = 2;  // resident workgroups per CU (QK_WGS_PER_CU)
   qk_stats last{};
 };
@@ -1751,292 +1751,6 @@ __global__ __launch_bounds__(64 * NW, OCC) void qk_sweep_duo_kernel(const SweepA
   }
 }
 
-// ----------------------------------------------------------------------------------------
-// v7: lean stream + duo.  zgemm_lstream is zgemm_lean generalised to a list of GEMM descriptors
-// (switching GEMM is just a rarer kind of pass change on both the fetch and the compute side), with
-// the B-operand conjugation applied as a sign on the staged imaginary plane and, for interleaved
-// chains, the visibility fence taken on the fetch side right before a GEMM's first tile is requested.
-// ----------------------------------------------------------------------------------------
-__device__ __forceinline__ void zgemm_lstream(const GemmDesc* __restrict__ descs, const int count, double* __restrict__ lds, const bool fence) {
-  constexpr int PM = 64, PN = 64, KTL = 16, NW = 8;
-  constexpr int APL = KTL * PM, STAGE_D = 4 * APL;
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int j = lane & 15, q = lane >> 4;
-  const int srow = tid >> 5, scol = (tid & 31) * 2;
-  double* st0 = lds + 2 * tid;
-  double* st1 = st0 + STAGE_D;
-
-  int total = 0;
-  for (int g = 0; g < count; ++g) {
-    const int M = qk_uniform_i(descs[g].M), N = qk_uniform_i(descs[g].N), K = qk_uniform_i(descs[g].Ktrue);
-    total += ((M + PM - 1) / PM) * ((N + PN - 1) / PN) * ((K + KTL - 1) / KTL);
-  }
-
-  // ---- fetch side
-  int f_g = 0, f_pm = 0, f_pn = 0, f_left = 0, f_npm = 0, f_npn = 0, f_nk = 0, f_M = 0, f_N = 0;
-  const double *gA_re, *gA_im, *gB_re, *gB_im;       // operand bases of the fetch-side GEMM
-  const double *fa_re, *fa_im, *fb_re, *fb_im;       // running pointers
-  long long sA = 0, sB = 0;
-  unsigned rA = 0, rB = 0, offA = 0, offB = 0;
-  double f_sgn = 1.0, sgn0 = 1.0, sgn1 = 1.0;
-  bool f_new = false;
-  auto fetch_pass_setup = [&]() __attribute__((always_inline)) {
-    const int m0 = f_pm * PM, n0 = f_pn * PN;
-    fa_re = gA_re + m0, fa_im = gA_im + m0, fb_re = gB_re + n0, fb_im = gB_im + n0;
-    offA = rA + (unsigned)min(scol, min(PM, f_M - m0) - 2);
-    offB = rB + (unsigned)min(scol, min(PN, f_N - n0) - 2);
-    f_left = f_nk;
-  };
-  auto fetch_gemm_setup = [&](int g) __attribute__((always_inline)) {
-    const GemmDesc* d = descs + g;
-    gA_re = reinterpret_cast<const double*>(qk_uniform_ll(reinterpret_cast<long long>(d->Are)));
-    gA_im = gA_re + qk_uniform_ll(d->a_plane);
-    gB_re = reinterpret_cast<const double*>(qk_uniform_ll(reinterpret_cast<long long>(d->Bre)));
-    gB_im = gB_re + qk_uniform_ll(d->b_plane);
-    const int lda = qk_uniform_i(d->lda), ldb = qk_uniform_i(d->ldb);
-    sA = (long long)KTL * lda, sB = (long long)KTL * ldb;
-    rA = (unsigned)(srow * lda), rB = (unsigned)(srow * ldb);
-    f_M = qk_uniform_i(d->M), f_N = qk_uniform_i(d->N);
-    f_nk = (qk_uniform_i(d->Ktrue) + KTL - 1) / KTL;
-    f_npm = (f_M + PM - 1) / PM, f_npn = (f_N + PN - 1) / PN;
-    f_sgn = qk_uniform_i(d->conjb) ? -1.0 : 1.0;
-    f_pm = f_pn = 0;
-    fetch_pass_setup();
-  };
-  auto fetch_advance = [&]() __attribute__((always_inline)) {  // called when the fetch-side pass is exhausted
-    if (++f_pm == f_npm) f_pm = 0, ++f_pn;
-    if (f_pn < f_npn) {
-      fetch_pass_setup();
-    } else if (++f_g < count) {
-      fetch_gemm_setup(f_g);
-      f_new = true;
-    }
-  };
-  fetch_gemm_setup(0);
-  double2 a0r, a0i, b0r, b0i, a1r, a1i, b1r, b1i;
-#define QK_LFETCH(AR, AI, BR, BI, SG)                          \
-  do {                                                         \
-    if (fence && f_new) {                                      \
-      __syncthreads();                                         \
-      f_new = false;                                           \
-    }                                                          \
-    SG = f_sgn;                                                \
-    AR = *reinterpret_cast<const double2*>(fa_re + offA);      \
-    AI = *reinterpret_cast<const double2*>(fa_im + offA);      \
-    BR = *reinterpret_cast<const double2*>(fb_re + offB);      \
-    BI = *reinterpret_cast<const double2*>(fb_im + offB);      \
-    fa_re += sA, fa_im += sA, fb_re += sB, fb_im += sB;        \
-    if (--f_left == 0) fetch_advance();                        \
-  } while (0)
-#define QK_LSTASH(ST, AR, AI, BR, BI, SG)                      \
-  do {                                                         \
-    *reinterpret_cast<double2*>(ST) = AR;                      \
-    *reinterpret_cast<double2*>(ST + APL) = AI;                \
-    *reinterpret_cast<double2*>(ST + 2 * APL) = BR;            \
-    *reinterpret_cast<double2*>(ST + 3 * APL) = make_double2(SG * BI.x, SG * BI.y); \
-  } while (0)
-
-  // ---- compute side
-  int c_g = 0, c_pm = 0, c_pn = 0, c_left = 0, cnt = 0, c_npm = 0, c_npn = 0, c_nk = 0, c_M = 0, c_N = 0, c_kslast = 4, c_ldc = 0, c_nhalf = 0;
-  long long c_jump = 0, crow = 0;
-  double *cCre, *cCim;
-  int la[2], lb[2];
-  long long co[2];
-  v4d cre[2], cim[2];
-  auto compute_pass_setup = [&]() __attribute__((always_inline)) {
-    const int m0 = c_pm * PM, n0 = c_pn * PN;
-    const int mt = min(PM / TILE, (c_M - m0) / TILE), nt = min(PN / TILE, (c_N - n0) / TILE);
-    const int vt = mt * nt;
-    cnt = (vt > wave) ? (vt - wave + NW - 1) / NW : 0;
-#pragma unroll
-    for (int e = 0; e < 2; ++e) {
-      const int t = min(wave + NW * e, vt - 1);
-      const int tm = t % mt, tn = t / mt;
-      la[e] = q * PM + tm * TILE + j;
-      lb[e] = 2 * APL + q * PN + tn * TILE + j;
-      const int col0 = n0 + tn * TILE;
-      co[e] = (long long)(m0 + tm * TILE + q) * c_ldc + col0 + j + (col0 >= c_nhalf ? c_jump : 0);
-      cre[e] = (v4d){0, 0, 0, 0};
-      cim[e] = (v4d){0, 0, 0, 0};
-    }
-    c_left = c_nk;
-  };
-  auto compute_gemm_setup = [&](int g) __attribute__((always_inline)) {
-    const GemmDesc* d = descs + g;
-    cCre = reinterpret_cast<double*>(qk_uniform_ll(reinterpret_cast<long long>(d->Cre)));
-    cCim = cCre + qk_uniform_ll(d->c_plane);
-    c_ldc = qk_uniform_i(d->ldc), c_nhalf = qk_uniform_i(d->n_half);
-    c_jump = qk_uniform_ll(d->c_jump);
-    crow = 4ll * c_ldc;
-    c_M = qk_uniform_i(d->M), c_N = qk_uniform_i(d->N);
-    const int K = qk_uniform_i(d->Ktrue);
-    c_nk = (K + KTL - 1) / KTL;
-    c_kslast = ((K + 3) >> 2) - (c_nk - 1) * (KTL / 4);
-    c_npm = (c_M + PM - 1) / PM, c_npn = (c_N + PN - 1) / PN;
-    c_pm = c_pn = 0;
-    compute_pass_setup();
-  };
-  compute_gemm_setup(0);
-  auto step = [&](const double* base) __attribute__((always_inline)) {
-    if (c_left > 1 || c_kslast == KTL / 4) {
-      mma_lean<false, true>(cre, cim, la, lb, base, cnt, KTL / 4);
-    } else {
-      mma_lean<false, false>(cre, cim, la, lb, base, cnt, c_kslast);
-    }
-    if (--c_left == 0) {
-#pragma unroll
-      for (int e = 0; e < 2; ++e) {
-        if (e < cnt) {
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            cCre[co[e] + r * crow] = cre[e][r];
-            cCim[co[e] + r * crow] = cim[e][r];
-          }
-        }
-      }
-      if (++c_pm == c_npm) c_pm = 0, ++c_pn;
-      if (c_pn < c_npn) {
-        compute_pass_setup();
-      } else if (++c_g < count) {
-        compute_gemm_setup(c_g);
-      }
-    }
-  };
-
-  QK_LFETCH(a0r, a0i, b0r, b0i, sgn0);
-  if (total > 1) QK_LFETCH(a1r, a1i, b1r, b1i, sgn1);
-  QK_LSTASH(st0, a0r, a0i, b0r, b0i, sgn0);
-  qk_lds_barrier();
-  int s = 0;
-  while (s + 3 < total) {
-    QK_LFETCH(a0r, a0i, b0r, b0i, sgn0);
-    step(lds);
-    QK_LSTASH(st1, a1r, a1i, b1r, b1i, sgn1);
-    qk_lds_barrier();
-    QK_LFETCH(a1r, a1i, b1r, b1i, sgn1);
-    step(lds + STAGE_D);
-    QK_LSTASH(st0, a0r, a0i, b0r, b0i, sgn0);
-    qk_lds_barrier();
-    s += 2;
-  }
-  for (; s < total; ++s) {
-    const bool even = (s & 1) == 0;
-    if (s + 2 < total) {
-      if (even) QK_LFETCH(a0r, a0i, b0r, b0i, sgn0); else QK_LFETCH(a1r, a1i, b1r, b1i, sgn1);
-    }
-    step(even ? lds : lds + STAGE_D);
-    if (s + 1 < total) {
-      if (even) QK_LSTASH(st1, a1r, a1i, b1r, b1i, sgn1); else QK_LSTASH(st0, a0r, a0i, b0r, b0i, sgn0);
-    }
-    qk_lds_barrier();
-  }
-#undef QK_LFETCH
-#undef QK_LSTASH
-  __syncthreads();
-}
-
-// the duo kernel's pair handling around the lean stream
-template <int OCC>
-__global__ __launch_bounds__(512, OCC) void qk_sweep_lduo_kernel(const SweepArgs g) {
-  using G = GemmCfg<64, 16, 8, 64>;
-  constexpr int T = 512, PN = 64, KTL = 16;
-  extern __shared__ __attribute__((aligned(16))) double lds[];
-  long long* slot = reinterpret_cast<long long*>(lds + G::LDS_D);
-  const int n = g.n_sites, n1 = n + 1;
-  GemmDesc* desc = reinterpret_cast<GemmDesc*>(slot + 2);            // [4]
-  int* flags = reinterpret_cast<int*>(desc + 4);                    // [2]: interleave ok, pad
-  long long* m_xo = reinterpret_cast<long long*>(flags + 2);        // [2][n]
-  long long* m_yo = m_xo + 2 * n;                                   // [2][n]
-  int* m_xd = reinterpret_cast<int*>(m_yo + 2 * n);                 // [2][n1] each below
-  int* m_yd = m_xd + 2 * n1;
-  int* m_xt = m_yd + 2 * n1;
-  int* m_yt = m_xt + 2 * n1;
-
-  const long long chain_stride = 2 * (g.x_plane + g.t_plane);
-  double* base = g.scratch + (long long)blockIdx.x * 2 * chain_stride;
-  const int tid = threadIdx.x;
-
-  for (;;) {
-    if (tid == 0) *slot = (long long)atomicAdd(g.counter, 1ull);
-    __syncthreads();
-    const long long gi = *slot;
-    __syncthreads();
-    const long long p0 = 2 * gi;
-    if (p0 >= g.npairs) break;
-    const int nch = (p0 + 1 < g.npairs) ? 2 : 1;
-    for (int e = tid; e < nch * n1; e += T) {
-      const int c = e / n1, k = e - c * n1;
-      const int xi = g.pairs[2 * (p0 + c)], yj = g.pairs[2 * (p0 + c) + 1];
-      m_xd[c * n1 + k] = g.xdims[(long long)xi * n1 + k];
-      m_yd[c * n1 + k] = g.ydims[(long long)yj * n1 + k];
-      m_xt[c * n1 + k] = g.xtrue[(long long)xi * n1 + k];
-      m_yt[c * n1 + k] = g.ytrue[(long long)yj * n1 + k];
-      if (k < n) {
-        m_xo[c * n + k] = g.xoffs[(long long)xi * n + k];
-        m_yo[c * n + k] = g.yoffs[(long long)yj * n + k];
-      }
-    }
-    __syncthreads();
-    for (int c = 0; c < nch; ++c) {
-      double* Xre = base + c * chain_stride;
-      double* Xim = Xre + g.x_plane;
-      const int ab = qk_uniform_i(m_xd[c * n1]) * qk_uniform_i(m_yd[c * n1]);
-      for (int e = tid; e < ab; e += T) {
-        Xre[e] = (e == 0) ? 1.0 : 0.0;
-        Xim[e] = 0.0;
-      }
-    }
-    __syncthreads();
-    for (int k = 0; k < n; ++k) {
-      if (tid < nch) {
-        const int c = tid;
-        double* Xre = base + c * chain_stride;
-        double* Xim = Xre + g.x_plane;
-        double* Tre = Xim + g.x_plane;
-        double* Tim = Tre + g.t_plane;
-        const int a = m_xd[c * n1 + k], a2 = m_xd[c * n1 + k + 1], b = m_yd[c * n1 + k], b2 = m_yd[c * n1 + k + 1];
-        GemmDesc& d1 = desc[c];          // phase 1: T[a x 2 b2] = X^T B
-        d1.Cre = Tre, d1.c_plane = Tim - Tre, d1.ldc = 2 * b2, d1.n_half = 2 * b2, d1.c_jump = 0;
-        d1.Are = Xre, d1.a_plane = Xim - Xre, d1.lda = a;
-        d1.Bre = g.ydata + m_yo[c * n + k], d1.b_plane = (long long)b * 2 * b2, d1.ldb = 2 * b2;
-        d1.M = a, d1.N = 2 * b2, d1.Ktrue = m_yt[c * n1 + k], d1.conjb = 0;
-        GemmDesc& d2 = desc[nch + c];    // phase 2: X'[b2 x a2] = T^T conj(A)
-        d2.Cre = Xre, d2.c_plane = Xim - Xre, d2.ldc = a2, d2.n_half = a2, d2.c_jump = 0;
-        d2.Are = Tre, d2.a_plane = Tim - Tre, d2.lda = b2;
-        d2.Bre = g.xdata + m_xo[c * n + k], d2.b_plane = (long long)a * 2 * a2, d2.ldb = a2;
-        d2.M = b2, d2.N = a2, d2.Ktrue = 2 * m_xt[c * n1 + k], d2.conjb = 1;
-      }
-      __syncthreads();
-      bool inter = (nch == 2);
-      if (inter) {  // every GEMM of the interleaved stream needs at least two steps (see zgemm_stream)
-        for (int i = 0; i < 4; ++i) {
-          const int M = qk_uniform_i(desc[i].M), N = qk_uniform_i(desc[i].N), K = qk_uniform_i(desc[i].Ktrue);
-          const int steps = ((M + G::PM - 1) / G::PM) * ((N + PN - 1) / PN) * ((K + KTL - 1) / KTL);
-          inter = inter && steps >= 2;
-        }
-      }
-      if (inter) {
-        zgemm_lstream(desc, 4, lds, true);
-      } else {
-        for (int i = 0; i < 2 * nch; ++i) zgemm_lstream(desc + i, 1, lds, false);
-      }
-    }
-    if (tid < nch) {
-      const double* Xre = base + tid * chain_stride;
-      const double re = Xre[0], im = Xre[g.x_plane];
-      g.values[p0 + tid] = re * re + im * im;
-      if (g.z) {
-        g.z[2 * (p0 + tid)] = re;
-        g.z[2 * (p0 + tid) + 1] = im;
-      }
-    }
-    __syncthreads();
-  }
-}
-
-
 template <int PN, int KTL, bool PROF = false, int NW = 4, int PMT = 64>
 __global__ __launch_bounds__(64 * NW, 2) void qk_sweep_flat_kernel(const SweepArgs g) {
   using G = GemmCfg<PN, KTL, NW, PMT>;
@@ -2241,7 +1955,6 @@ extern "C" int qk_ctx_create(int device_id, qk_ctx** out) {
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(qk_sweep_group_kernel<64, 16, 4, 8, 64>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(qk_sweep_duo_kernel<64, 16, 4, 8, 64>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(qk_sweep_lean_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
-  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(qk_sweep_lduo_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(qk_mma_bench_kernel<4, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)GemmCfg<64, 16, 4, 64>::LDS_B));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(qk_mma_bench_kernel<4, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)GemmCfg<64, 16, 4, 64>::LDS_B));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(qk_mma_bench_kernel<4, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)GemmCfg<64, 16, 4, 64>::LDS_B));
@@ -2414,7 +2127,7 @@ extern "C" int qk_gram_values(qk_ctx* c, const qk_mps_set* xs, const qk_mps_set*
   if (rc != QK_OK) return rc;
 
   const bool grouped = (c->variant == 14);
-  const bool duo = (c->variant == 16 || c->variant == 18);
+  const bool duo = (c->variant == 16);
   const long long members = grouped ? GMAX : 1;  // pairs stacked in one X/T buffer
   const long long chains = duo ? 2 : 1;          // independent X/T buffer sets per workgroup
   const long long x_plane = members * xs->max_pad * ys->max_pad;
@@ -2467,13 +2180,11 @@ extern "C" int qk_gram_values(qk_ctx* c, const qk_mps_set* xs, const qk_mps_set*
       qk_sweep_group_kernel<64, 16, 4, 8, 64><<<dim3(grid), dim3(512), lds_group, c->stream>>>(a);
       break;
     }
-    case 16:
-    case 18: {  // duo sweep: two independent pairs per workgroup, phases interleaved in one stream (18 = lean steps)
+    case 16: {  // duo sweep: two independent pairs per workgroup, phases interleaved in one stream
       const int ns = xs->n_sites;
       const size_t lds_duo = lds_b + 16 + 4 * sizeof(GemmDesc) + 8 + (size_t)4 * ns * sizeof(long long) + (size_t)8 * (ns + 1) * sizeof(int);
       if (lds_duo > 80 * 1024) return fail(QK_EINVAL, "qk_gram_values: %d sites need %zu bytes of LDS per workgroup", ns, lds_duo);
-      if (c->variant == 18) qk_sweep_lduo_kernel<4><<<dim3(grid), dim3(512), lds_duo, c->stream>>>(a);
-      else qk_sweep_duo_kernel<64, 16, 4, 8, 64><<<dim3(grid), dim3(512), lds_duo, c->stream>>>(a);
+      qk_sweep_duo_kernel<64, 16, 4, 8, 64><<<dim3(grid), dim3(512), lds_duo, c->stream>>>(a);
       break;
     }
     case 19:  // diagnostic: instrumented shipped kernel
