@@ -13,6 +13,7 @@
 #include "../../include/qkgram.h"
 
 #include <hip/hip_runtime.h>
+#include <type_traits>
 
 #include <algorithm>
 #include <cmath>
@@ -1198,8 +1199,186 @@ __device__ __forceinline__ void zgemm_lean(double* __restrict__ Cre, double* __r
   __syncthreads();
 }
 
+// ----------------------------------------------------------------------------------------
+// v8: ring GEMM.  Same 64x64 pass / 8-wave / 2-tiles-per-wave decomposition as zgemm_lean, but
+//   * staging is LDS-DMA (global_load_lds, 16 B per lane) into a ring of three K-tile-8 slots, two
+//     K-tiles in flight across the raw barrier, retired by a counted s_waitcnt vmcnt -- no staging
+//     registers and no ds_write pass;
+//   * the registers this frees hold a third accumulator per tile, so the complex product is the 3M form
+//       P1 += ar*br, P2 += ai*bi, P3 += (ar+ai)*(br+sbi),  sbi = +bi (plain) | -bi (conjugated B)
+//       re = P1 - P2 | P1 + P2,   im = P3 - P1 - P2 | P3 - P1 + P2
+//     three MFMAs per complex k-step instead of four (operand sums: two v_add_f64 on the fragments).
+// Staging roles: waves 0-3 bring the re planes, waves 4-7 the im planes; wave w covers K rows
+// 2(w&3), 2(w&3)+1 of both operands (one 1-KiB wave-linear piece of the A plane and one of the B plane).
+// ----------------------------------------------------------------------------------------
+__device__ __forceinline__ void qk_wait_vm(const int n) {  // n in {0, 2, 8, 10, 16, 18}, wave-uniform
+  if (n == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+  else if (n == 10) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+  else if (n == 18) asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
+  else if (n == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  else if (n == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+// One complex k-step of one tile in 3M form (three independent accumulators, so no MFMA waits on the previous one).
+template <bool CONJB>
+__device__ __forceinline__ void mma3_kstep(v4d& c1, v4d& c2, v4d& c3, const double ar, const double ai, const double br, const double bi) {
+  const double sa = ar + ai, sb = CONJB ? br - bi : br + bi;
+  c1 = __builtin_amdgcn_mfma_f64_16x16x4f64(ar, br, c1, 0, 0, 0);
+  c2 = __builtin_amdgcn_mfma_f64_16x16x4f64(ai, bi, c2, 0, 0, 0);
+  c3 = __builtin_amdgcn_mfma_f64_16x16x4f64(sa, sb, c3, 0, 0, 0);
+}
+
+template <bool CONJB, int CNT, bool FULLK>
+__device__ __forceinline__ void mma_ring3(v4d (&c1)[2], v4d (&c2)[2], v4d (&c3)[2], const int (&la)[2], const int (&lb)[2],
+                                          const double* __restrict__ base) {
+  constexpr int PMN = 64, APL = 8 * 64;  // staged planes: A re | A im | B re | B im
+  if constexpr (CNT == 0) return;
+  if constexpr (FULLK) {
+    double far[2], fai[2], fbr[2], fbi[2];
+    auto load = [&](int g, int buf) __attribute__((always_inline)) {
+      const int e = g >> 1, ks = g & 1;
+      const double* pa = base + la[e] + 4 * ks * PMN;
+      const double* pb = base + lb[e] + 4 * ks * PMN;
+      far[buf] = pa[0];
+      fai[buf] = pa[APL];
+      fbr[buf] = pb[0];
+      fbi[buf] = pb[APL];
+    };
+    load(0, 0);
+#pragma unroll
+    for (int g = 0; g < 2 * CNT; ++g) {
+      const int e = g >> 1;
+      if (g + 1 < 2 * CNT) load(g + 1, (g + 1) & 1);
+      __builtin_amdgcn_sched_barrier(0);
+      mma3_kstep<CONJB>(c1[e], c2[e], c3[e], far[g & 1], fai[g & 1], fbr[g & 1], fbi[g & 1]);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  } else {  // a single k-step (the tail of a K range that is an odd multiple of 4)
+#pragma unroll
+    for (int e = 0; e < CNT; ++e) {
+      const double* pa = base + la[e];
+      const double* pb = base + lb[e];
+      mma3_kstep<CONJB>(c1[e], c2[e], c3[e], pa[0], pa[APL], pb[0], pb[APL]);
+    }
+  }
+}
+
+template <bool CONJB>
+__device__ __forceinline__ void zgemm_ring3(double* __restrict__ Cre, double* __restrict__ Cim, const int ldc,
+                                            const double* __restrict__ Are, const double* __restrict__ Aim, const int lda,
+                                            const double* __restrict__ Bre, const double* __restrict__ Bim, const int ldb,
+                                            const int M, const int N, const int Ktrue, double* __restrict__ lds) {
+  constexpr int PM = 64, PN = 64, KTL = 8, NW = 8;
+  constexpr int APL = KTL * PM, SLOT_D = 4 * APL;  // doubles per plane / per ring slot (16 KiB)
+  typedef __attribute__((address_space(3))) void* lds_ptr_t;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int j = lane & 15, q = lane >> 4;
+  const int npm = (M + PM - 1) / PM, npn = (N + PN - 1) / PN;
+  const int nk = (Ktrue + KTL - 1) / KTL;
+  const bool last_full = (((Ktrue + 3) >> 2) & 1) == 0;  // the last K-tile holds two k-steps (else one)
+  const int total = npm * npn * nk;
+  const long long sA = (long long)KTL * lda, sB = (long long)KTL * ldb;
+
+  // ---- staging role of this wave / lane
+  const int w3 = wave & 3, pl = wave >> 2;
+  const double* const Asrc = pl ? Aim : Are;
+  const double* const Bsrc = pl ? Bim : Bre;
+  const int srow = 2 * w3 + (lane >> 5), scol = (lane & 31) * 2;
+  const unsigned rA = (unsigned)(srow * lda), rB = (unsigned)(srow * ldb);
+  double* const dA = lds + pl * APL + w3 * 128;        // slot 0 destinations (wave-uniform)
+  double* const dB = lds + (2 + pl) * APL + w3 * 128;
+
+  // ---- fetch-side pass state (runs two K-tiles ahead of the compute side, across pass boundaries)
+  int f_pm = 0, f_pn = 0, f_left = nk, f_slot = 0;
+  const double *fa = Asrc, *fb = Bsrc;
+  unsigned offA = rA + (unsigned)min(scol, min(PM, M) - 2), offB = rB + (unsigned)min(scol, min(PN, N) - 2);
+  auto fetch = [&]() __attribute__((always_inline)) {
+    __builtin_amdgcn_global_load_lds(fa + offA, (lds_ptr_t)(dA + f_slot), 16, 0, 0);
+    __builtin_amdgcn_global_load_lds(fb + offB, (lds_ptr_t)(dB + f_slot), 16, 0, 0);
+    fa += sA, fb += sB;
+    f_slot = (f_slot == 2 * SLOT_D) ? 0 : f_slot + SLOT_D;
+    if (--f_left == 0) {
+      if (++f_pm == npm) f_pm = 0, ++f_pn;
+      const int m0 = f_pm * PM, n0 = f_pn * PN;
+      fa = Asrc + m0, fb = Bsrc + n0;
+      offA = rA + (unsigned)min(scol, min(PM, M - m0) - 2);
+      offB = rB + (unsigned)min(scol, min(PN, N - n0) - 2);
+      f_left = nk;
+    }
+  };
+
+  // ---- step counters shared by all passes
+  int s = 0, c_slot = 0, pend = 0;
+  const int crow = 4 * ldc;
+
+  // One pass = nk steps on one 64x64 output tile, specialised on the number of tiles this wave owns so that
+  // the MFMA block is branch-free and the accumulators live only inside the pass.
+  auto run_pass = [&](auto cnt_tag, const int m0, const int n0, const int mt, const int vt) __attribute__((always_inline)) {
+    constexpr int CNT = decltype(cnt_tag)::value;
+    int la[2], lb[2], co[2];
+    v4d c1[2], c2[2], c3[2];
+    const int inv = (mt == 1) ? 32 : (mt == 2) ? 16 : (mt == 3) ? 11 : 8;  // t / mt == (t * inv) >> 5 for t < 16
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      const int t = min(wave + NW * e, vt - 1);
+      const int tn = (t * inv) >> 5, tm = t - tn * mt;
+      la[e] = q * PM + tm * TILE + j;
+      lb[e] = 2 * APL + q * PN + tn * TILE + j;
+      co[e] = (m0 + tm * TILE + q) * ldc + n0 + tn * TILE + j;
+      c1[e] = (v4d){0, 0, 0, 0};
+      c2[e] = (v4d){0, 0, 0, 0};
+      c3[e] = (v4d){0, 0, 0, 0};
+    }
+    for (int kt = 0; kt < nk; ++kt, ++s) {
+      const bool more = s + 2 < total;
+      if (more) fetch();                                 // K-tile s+2 -> the slot read in step s-1
+      const double* base = lds + c_slot;
+      if (kt + 1 < nk || last_full) mma_ring3<CONJB, CNT, true>(c1, c2, c3, la, lb, base);
+      else mma_ring3<CONJB, CNT, false>(c1, c2, c3, la, lb, base);
+      if (s + 1 < total) {                               // K-tile s+1 must have landed; everything issued after it may stay in flight
+        qk_wait_vm((more ? 2 : 0) + pend);
+        qk_lds_barrier();
+      }
+      pend = 0;
+      c_slot = (c_slot == 2 * SLOT_D) ? 0 : c_slot + SLOT_D;
+    }
+    if constexpr (CNT > 0) {
+#pragma unroll
+      for (int e = 0; e < CNT; ++e) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const double p1 = c1[e][r], p2 = c2[e][r], p3 = c3[e][r];
+          Cre[co[e] + r * crow] = CONJB ? p1 + p2 : p1 - p2;
+          Cim[co[e] + r * crow] = CONJB ? (p3 - p1) + p2 : (p3 - p1) - p2;
+        }
+      }
+      pend = 8 * CNT;
+    }
+  };
+
+  fetch();
+  if (total > 1) fetch();
+  qk_wait_vm(total > 1 ? 2 : 0);
+  qk_lds_barrier();
+  for (int pn = 0; pn < npn; ++pn) {
+    for (int pm = 0; pm < npm; ++pm) {
+      const int m0 = pm * PM, n0 = pn * PN;
+      const int mt = min(PM / TILE, (M - m0) / TILE), nt = min(PN / TILE, (N - n0) / TILE);
+      const int vt = mt * nt;
+      const int cnt = (vt > wave) ? (vt - wave + NW - 1) / NW : 0;
+      if (cnt == 2) run_pass(std::integral_constant<int, 2>{}, m0, n0, mt, vt);
+      else if (cnt == 1) run_pass(std::integral_constant<int, 1>{}, m0, n0, mt, vt);
+      else run_pass(std::integral_constant<int, 0>{}, m0, n0, mt, vt);
+    }
+  }
+  __syncthreads();
+}
+
 // the deep kernel's pair loop around the lean GEMM
-template <int OCC>
+template <int OCC, bool RING = false>
 __global__ __launch_bounds__(512, OCC) void qk_sweep_lean_kernel(const SweepArgs g) {
   using G = GemmCfg<64, 16, 8, 64>;
   constexpr int NW = 8;
@@ -1265,8 +1444,13 @@ __global__ __launch_bounds__(512, OCC) void qk_sweep_lean_kernel(const SweepArgs
       const double* Aim = Are + (long long)a * 2 * a2;
       const double* Bre = g.ydata + ldl(m_yo + k);
       const double* Bim = Bre + (long long)b * 2 * b2;
-      zgemm_lean<false>(Tre, Tim, 2 * b2, Xre, Xim, a, Bre, Bim, 2 * b2, a, 2 * b2, ldi(m_yt + k), lds);
-      zgemm_lean<true>(Xre, Xim, a2, Tre, Tim, b2, Are, Aim, a2, b2, a2, 2 * ldi(m_xt + k), lds);
+      if constexpr (RING) {
+        zgemm_ring3<false>(Tre, Tim, 2 * b2, Xre, Xim, a, Bre, Bim, 2 * b2, a, 2 * b2, ldi(m_yt + k), lds);
+        zgemm_ring3<true>(Xre, Xim, a2, Tre, Tim, b2, Are, Aim, a2, b2, a2, 2 * ldi(m_xt + k), lds);
+      } else {
+        zgemm_lean<false>(Tre, Tim, 2 * b2, Xre, Xim, a, Bre, Bim, 2 * b2, a, 2 * b2, ldi(m_yt + k), lds);
+        zgemm_lean<true>(Xre, Xim, a2, Tre, Tim, b2, Are, Aim, a2, b2, a2, 2 * ldi(m_xt + k), lds);
+      }
     }
     if (tid == 0) {
       const double re = Xre[0], im = Xim[0];
@@ -1955,6 +2139,7 @@ extern "C" int qk_ctx_create(int device_id, qk_ctx** out) {
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(qk_sweep_group_kernel<64, 16, 4, 8, 64>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(qk_sweep_duo_kernel<64, 16, 4, 8, 64>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(qk_sweep_lean_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(qk_sweep_lean_kernel<4, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(qk_mma_bench_kernel<4, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)GemmCfg<64, 16, 4, 64>::LDS_B));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(qk_mma_bench_kernel<4, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)GemmCfg<64, 16, 4, 64>::LDS_B));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(qk_mma_bench_kernel<4, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)GemmCfg<64, 16, 4, 64>::LDS_B));
@@ -2196,6 +2381,9 @@ extern "C" int qk_gram_values(qk_ctx* c, const qk_mps_set* xs, const qk_mps_set*
       break;
     case 13:  // two-step-deep prefetch, 8 waves (2 tiles per wave, 16 waves per CU)
       qk_sweep_deep_kernel<64, 16, 4, 8, 64><<<dim3(grid), dim3(512), lds_deep, c->stream>>>(a);
+      break;
+    case 20:  // ring kernel: LDS-DMA staging ring + 3M complex product
+      qk_sweep_lean_kernel<4, true><<<dim3(grid), dim3(512), lds_deep, c->stream>>>(a);
       break;
     default:  // 17: the shipped kernel -- same pipeline with the lean steady-state step
       qk_sweep_lean_kernel<4><<<dim3(grid), dim3(512), lds_deep, c->stream>>>(a);

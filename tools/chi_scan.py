@@ -25,7 +25,8 @@ def main():
     rng = np.random.default_rng(0)
     ctx = engine.Context(0)
     print(f"{'chi':>5} {'pairs':>6} {'ms':>9} {'alg TF/s':>9} {'pad TF/s':>9} {'pad/peak':>8} {'us/pair/WG':>10}")
-    for chi in (4, 16, 32, 48, 64, 96, 128, 192):
+    chis = [int(c) for c in os.environ.get("QK_CHIS", "4,16,32,48,64,96,128,192").split(",")]
+    for chi in chis:
         m0 = Q.random_mps(n, profile(n, chi), rng)
         # identical tensors for every state are fine for timing; perturb one entry so states differ
         states = [m0] * ns
