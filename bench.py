@@ -276,7 +276,7 @@ def main():
             },
             "roofline": {
                 "bound": "mfma",
-                "kernel": "qk_sweep_lean_kernel<4>",
+                "kernel": "qk_sweep_lean_kernel<4, 1>",
                 "achieved": achieved,
                 "peak": PEAK_F64_MFMA_TFLOPS,
                 "unit": "TFLOP/s",

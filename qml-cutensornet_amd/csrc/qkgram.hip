@@ -66,7 +66,8 @@ struct qk_ctx {
   size_t scratch_bytes = 0;
   unsigned long long* counter = nullptr;
   unsigned long long* prof = nullptr;  // 8 cycle sums of the diagnostic variant
-  int variant = 17;    // sweep kernel variant (QK_VARIANT): 17 = shipped (lean deep-prefetch sweep, 8 waves); 0, 2, 12, 13, 14, 16 = other kernels kept for A/B; 9, 19 = instrumented
+  int variant = 20;    // sweep kernel variant (QK_VARIANT): 20 = shipped (ring sweep: LDS-DMA ring + 3M product); 17 = lean register-staged sweep;
+                       // 0, 2, 12, 13, 14, 16, 21, 23 = other kernels kept for A/B; 9, 19 = instrumented
   int wgs_per_cu = 2;  // resident workgroups per CU (QK_WGS_PER_CU)
   qk_stats last{};
 };
@@ -1211,66 +1212,104 @@ __device__ __forceinline__ void zgemm_lean(double* __restrict__ Cre, double* __r
 // Staging roles: waves 0-3 bring the re planes, waves 4-7 the im planes; wave w covers K rows
 // 2(w&3), 2(w&3)+1 of both operands (one 1-KiB wave-linear piece of the A plane and one of the B plane).
 // ----------------------------------------------------------------------------------------
-__device__ __forceinline__ void qk_wait_vm(const int n) {  // n in {0, 2, 8, 10, 16, 18}, wave-uniform
-  if (n == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-  else if (n == 10) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
-  else if (n == 18) asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
-  else if (n == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-  else if (n == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+__device__ __forceinline__ void qk_wait_vm(const int n) {  // wave-uniform n; values above 24 wait for everything
+  switch (n) {
+    case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+    case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+    case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+    case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+    case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+    case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+    case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
+    case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+    case 9: asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); break;
+    case 10: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
+    case 11: asm volatile("s_waitcnt vmcnt(11)" ::: "memory"); break;
+    case 12: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
+    case 13: asm volatile("s_waitcnt vmcnt(13)" ::: "memory"); break;
+    case 14: asm volatile("s_waitcnt vmcnt(14)" ::: "memory"); break;
+    case 15: asm volatile("s_waitcnt vmcnt(15)" ::: "memory"); break;
+    case 16: asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); break;
+    case 17: asm volatile("s_waitcnt vmcnt(17)" ::: "memory"); break;
+    case 18: asm volatile("s_waitcnt vmcnt(18)" ::: "memory"); break;
+    case 19: asm volatile("s_waitcnt vmcnt(19)" ::: "memory"); break;
+    case 20: asm volatile("s_waitcnt vmcnt(20)" ::: "memory"); break;
+    case 21: asm volatile("s_waitcnt vmcnt(21)" ::: "memory"); break;
+    case 22: asm volatile("s_waitcnt vmcnt(22)" ::: "memory"); break;
+    case 23: asm volatile("s_waitcnt vmcnt(23)" ::: "memory"); break;
+    case 24: asm volatile("s_waitcnt vmcnt(24)" ::: "memory"); break;
+    default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+  }
 }
 
-// One complex k-step of one tile in 3M form (three independent accumulators, so no MFMA waits on the previous one).
-template <bool CONJB>
+// One complex k-step of one tile.  M3: 3M form (three independent accumulators c1 = P1, c2 = P2, c3 = P3);
+// otherwise the plain four-product form (c1 = re, c2 = im, c3 unused).
+template <bool CONJB, bool M3>
 __device__ __forceinline__ void mma3_kstep(v4d& c1, v4d& c2, v4d& c3, const double ar, const double ai, const double br, const double bi) {
-  const double sa = ar + ai, sb = CONJB ? br - bi : br + bi;
-  c1 = __builtin_amdgcn_mfma_f64_16x16x4f64(ar, br, c1, 0, 0, 0);
-  c2 = __builtin_amdgcn_mfma_f64_16x16x4f64(ai, bi, c2, 0, 0, 0);
-  c3 = __builtin_amdgcn_mfma_f64_16x16x4f64(sa, sb, c3, 0, 0, 0);
+  if constexpr (M3) {
+    const double sa = ar + ai, sb = CONJB ? br - bi : br + bi;
+    c1 = __builtin_amdgcn_mfma_f64_16x16x4f64(ar, br, c1, 0, 0, 0);
+    c2 = __builtin_amdgcn_mfma_f64_16x16x4f64(ai, bi, c2, 0, 0, 0);
+    c3 = __builtin_amdgcn_mfma_f64_16x16x4f64(sa, sb, c3, 0, 0, 0);
+  } else {
+    const double sbi = CONJB ? -bi : bi;
+    c1 = __builtin_amdgcn_mfma_f64_16x16x4f64(ar, br, c1, 0, 0, 0);
+    c2 = __builtin_amdgcn_mfma_f64_16x16x4f64(ar, sbi, c2, 0, 0, 0);
+    c1 = __builtin_amdgcn_mfma_f64_16x16x4f64(-ai, sbi, c1, 0, 0, 0);
+    c2 = __builtin_amdgcn_mfma_f64_16x16x4f64(ai, br, c2, 0, 0, 0);
+  }
 }
 
-template <bool CONJB, int CNT, bool FULLK>
+template <bool CONJB, int CNT, bool FULLK, bool M3, int KTL, int PN = 64>
 __device__ __forceinline__ void mma_ring3(v4d (&c1)[2], v4d (&c2)[2], v4d (&c3)[2], const int (&la)[2], const int (&lb)[2],
-                                          const double* __restrict__ base) {
-  constexpr int PMN = 64, APL = 8 * 64;  // staged planes: A re | A im | B re | B im
+                                          const double* __restrict__ base, const int ksteps) {
+  constexpr int PM = 64, APL = KTL * PM, BPL = KTL * PN, KS = KTL / 4;  // staged planes: A re | A im | B re | B im
   if constexpr (CNT == 0) return;
   if constexpr (FULLK) {
     double far[2], fai[2], fbr[2], fbi[2];
     auto load = [&](int g, int buf) __attribute__((always_inline)) {
-      const int e = g >> 1, ks = g & 1;
-      const double* pa = base + la[e] + 4 * ks * PMN;
-      const double* pb = base + lb[e] + 4 * ks * PMN;
+      const int e = g / KS, ks = g % KS;
+      const double* pa = base + la[e] + 4 * ks * PM;
+      const double* pb = base + lb[e] + 4 * ks * PN;
       far[buf] = pa[0];
       fai[buf] = pa[APL];
       fbr[buf] = pb[0];
-      fbi[buf] = pb[APL];
+      fbi[buf] = pb[BPL];
     };
     load(0, 0);
 #pragma unroll
-    for (int g = 0; g < 2 * CNT; ++g) {
-      const int e = g >> 1;
-      if (g + 1 < 2 * CNT) load(g + 1, (g + 1) & 1);
+    for (int g = 0; g < KS * CNT; ++g) {
+      const int e = g / KS;
+      if (g + 1 < KS * CNT) load(g + 1, (g + 1) & 1);
       __builtin_amdgcn_sched_barrier(0);
-      mma3_kstep<CONJB>(c1[e], c2[e], c3[e], far[g & 1], fai[g & 1], fbr[g & 1], fbi[g & 1]);
+      mma3_kstep<CONJB, M3>(c1[e], c2[e], c3[e], far[g & 1], fai[g & 1], fbr[g & 1], fbi[g & 1]);
       __builtin_amdgcn_sched_barrier(0);
     }
-  } else {  // a single k-step (the tail of a K range that is an odd multiple of 4)
+  } else {  // the last K-tile of a K range that does not fill it: ksteps in 1..KS-1
 #pragma unroll
     for (int e = 0; e < CNT; ++e) {
-      const double* pa = base + la[e];
-      const double* pb = base + lb[e];
-      mma3_kstep<CONJB>(c1[e], c2[e], c3[e], pa[0], pa[APL], pb[0], pb[APL]);
+#pragma unroll
+      for (int ks = 0; ks < KS - 1; ++ks) {
+        if (ks < ksteps) {
+          const double* pa = base + la[e] + 4 * ks * PM;
+          const double* pb = base + lb[e] + 4 * ks * PN;
+          mma3_kstep<CONJB, M3>(c1[e], c2[e], c3[e], pa[0], pa[APL], pb[0], pb[BPL]);
+        }
+      }
     }
   }
 }
 
-template <bool CONJB>
+template <bool CONJB, int KTL, int NSLOT, bool M3, int NW = 8, int PN = 64>
 __device__ __forceinline__ void zgemm_ring3(double* __restrict__ Cre, double* __restrict__ Cim, const int ldc,
                                             const double* __restrict__ Are, const double* __restrict__ Aim, const int lda,
                                             const double* __restrict__ Bre, const double* __restrict__ Bim, const int ldb,
                                             const int M, const int N, const int Ktrue, double* __restrict__ lds) {
-  constexpr int PM = 64, PN = 64, KTL = 8, NW = 8;
-  constexpr int APL = KTL * PM, SLOT_D = 4 * APL;  // doubles per plane / per ring slot (16 KiB)
+  static_assert((NW == 8 && PN == 64) || (NW == 4 && PN == 32 && KTL == 8), "supported shapes");
+  constexpr int PM = 64;
+  constexpr int APL = KTL * PM, BPL = KTL * PN, SLOT_D = 2 * APL + 2 * BPL;  // doubles per plane / per ring slot
+  constexpr int DEPTH = NSLOT - 1;                 // K-tiles in flight ahead of the one being multiplied
+  constexpr int LPS = (NW == 4) ? 3 : KTL / 4;     // LDS-DMA instructions per wave and K-tile
   typedef __attribute__((address_space(3))) void* lds_ptr_t;
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -1278,34 +1317,44 @@ __device__ __forceinline__ void zgemm_ring3(double* __restrict__ Cre, double* __
   const int j = lane & 15, q = lane >> 4;
   const int npm = (M + PM - 1) / PM, npn = (N + PN - 1) / PN;
   const int nk = (Ktrue + KTL - 1) / KTL;
-  const bool last_full = (((Ktrue + 3) >> 2) & 1) == 0;  // the last K-tile holds two k-steps (else one)
+  const int ks_last = ((Ktrue + 3) >> 2) - (nk - 1) * (KTL / 4);  // k-steps of the last K-tile (1..KTL/4)
   const int total = npm * npn * nk;
   const long long sA = (long long)KTL * lda, sB = (long long)KTL * ldb;
 
-  // ---- staging role of this wave / lane
-  const int w3 = wave & 3, pl = wave >> 2;
+  // ---- staging role of this wave / lane: 1-KiB wave-linear pieces of the staged planes.
+  // 8 waves, K-tile 8: waves 0-3 bring the re planes, waves 4-7 the im planes (K rows 2(w&3), +1 of A and of B).
+  // 8 waves, K-tile 16: every wave brings rows 2w, 2w+1 of all four planes.
+  // 4 waves (64x32 pass), K-tile 8: wave w brings rows 2w, 2w+1 of A re and A im, and one of the four 1-KiB pieces
+  // of the B planes (plane w>>1, K rows 4(w&1) .. +3; a B row is 32 doubles).
+  const int w3 = (NW == 8 && KTL == 8) ? (wave & 3) : wave;
+  const int pl = (NW == 8 && KTL == 8) ? (wave >> 2) : 0;
+  const long long a_im = Aim - Are, b_im = Bim - Bre;  // plane strides of the operands
   const double* const Asrc = pl ? Aim : Are;
-  const double* const Bsrc = pl ? Bim : Bre;
+  const double* const Bsrc = (NW == 4) ? ((wave >> 1) ? Bim : Bre) : (pl ? Bim : Bre);
   const int srow = 2 * w3 + (lane >> 5), scol = (lane & 31) * 2;
-  const unsigned rA = (unsigned)(srow * lda), rB = (unsigned)(srow * ldb);
+  const int srowB = (NW == 4) ? 4 * (wave & 1) + (lane >> 4) : srow;
+  const int scolB = (NW == 4) ? (lane & 15) * 2 : scol;
+  const unsigned rA = (unsigned)(srow * lda), rB = (unsigned)(srowB * ldb);
   double* const dA = lds + pl * APL + w3 * 128;        // slot 0 destinations (wave-uniform)
-  double* const dB = lds + (2 + pl) * APL + w3 * 128;
+  double* const dB = (NW == 4) ? lds + 2 * APL + (wave >> 1) * BPL + (wave & 1) * 128 : lds + 2 * APL + pl * BPL + w3 * 128;
 
-  // ---- fetch-side pass state (runs two K-tiles ahead of the compute side, across pass boundaries)
+  // ---- fetch-side pass state (runs DEPTH K-tiles ahead of the compute side, across pass boundaries)
   int f_pm = 0, f_pn = 0, f_left = nk, f_slot = 0;
   const double *fa = Asrc, *fb = Bsrc;
-  unsigned offA = rA + (unsigned)min(scol, min(PM, M) - 2), offB = rB + (unsigned)min(scol, min(PN, N) - 2);
+  unsigned offA = rA + (unsigned)min(scol, min(PM, M) - 2), offB = rB + (unsigned)min(scolB, min(PN, N) - 2);
   auto fetch = [&]() __attribute__((always_inline)) {
     __builtin_amdgcn_global_load_lds(fa + offA, (lds_ptr_t)(dA + f_slot), 16, 0, 0);
+    if constexpr (KTL == 16 || NW == 4) __builtin_amdgcn_global_load_lds(fa + a_im + offA, (lds_ptr_t)(dA + APL + f_slot), 16, 0, 0);
     __builtin_amdgcn_global_load_lds(fb + offB, (lds_ptr_t)(dB + f_slot), 16, 0, 0);
+    if constexpr (KTL == 16) __builtin_amdgcn_global_load_lds(fb + b_im + offB, (lds_ptr_t)(dB + BPL + f_slot), 16, 0, 0);
     fa += sA, fb += sB;
-    f_slot = (f_slot == 2 * SLOT_D) ? 0 : f_slot + SLOT_D;
+    f_slot = (f_slot == (NSLOT - 1) * SLOT_D) ? 0 : f_slot + SLOT_D;
     if (--f_left == 0) {
       if (++f_pm == npm) f_pm = 0, ++f_pn;
       const int m0 = f_pm * PM, n0 = f_pn * PN;
       fa = Asrc + m0, fb = Bsrc + n0;
       offA = rA + (unsigned)min(scol, min(PM, M - m0) - 2);
-      offB = rB + (unsigned)min(scol, min(PN, N - n0) - 2);
+      offB = rB + (unsigned)min(scolB, min(PN, N - n0) - 2);
       f_left = nk;
     }
   };
@@ -1332,36 +1381,43 @@ __device__ __forceinline__ void zgemm_ring3(double* __restrict__ Cre, double* __
       c2[e] = (v4d){0, 0, 0, 0};
       c3[e] = (v4d){0, 0, 0, 0};
     }
-    for (int kt = 0; kt < nk; ++kt, ++s) {
-      const bool more = s + 2 < total;
-      if (more) fetch();                                 // K-tile s+2 -> the slot read in step s-1
+    for (int kt = 0; kt < nk; ++kt, ++s) {  // (ring)
+      if (s + DEPTH < total) fetch();                    // K-tile s+DEPTH -> the slot read in step s-1
       const double* base = lds + c_slot;
-      if (kt + 1 < nk || last_full) mma_ring3<CONJB, CNT, true>(c1, c2, c3, la, lb, base);
-      else mma_ring3<CONJB, CNT, false>(c1, c2, c3, la, lb, base);
-      if (s + 1 < total) {                               // K-tile s+1 must have landed; everything issued after it may stay in flight
-        qk_wait_vm((more ? 2 : 0) + pend);
+      if (kt + 1 < nk || ks_last == KTL / 4) mma_ring3<CONJB, CNT, true, M3, KTL, PN>(c1, c2, c3, la, lb, base, KTL / 4);
+      else mma_ring3<CONJB, CNT, false, M3, KTL, PN>(c1, c2, c3, la, lb, base, ks_last);
+      if (s + 1 < total) {
+        // K-tile s+1 must have landed; everything issued after it may stay in flight: the younger K-tiles and,
+        // when it was issued before the previous step's epilogue (DEPTH >= 2), that epilogue's stores
+        qk_wait_vm(LPS * min(DEPTH - 1, total - 2 - s) + (DEPTH >= 2 ? pend : 0));
         qk_lds_barrier();
       }
       pend = 0;
-      c_slot = (c_slot == 2 * SLOT_D) ? 0 : c_slot + SLOT_D;
+      c_slot = (c_slot == (NSLOT - 1) * SLOT_D) ? 0 : c_slot + SLOT_D;
     }
     if constexpr (CNT > 0) {
 #pragma unroll
       for (int e = 0; e < CNT; ++e) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const double p1 = c1[e][r], p2 = c2[e][r], p3 = c3[e][r];
-          Cre[co[e] + r * crow] = CONJB ? p1 + p2 : p1 - p2;
-          Cim[co[e] + r * crow] = CONJB ? (p3 - p1) + p2 : (p3 - p1) - p2;
+          if constexpr (M3) {
+            const double p1 = c1[e][r], p2 = c2[e][r], p3 = c3[e][r];
+            Cre[co[e] + r * crow] = CONJB ? p1 + p2 : p1 - p2;
+            Cim[co[e] + r * crow] = CONJB ? (p3 - p1) + p2 : (p3 - p1) - p2;
+          } else {
+            Cre[co[e] + r * crow] = c1[e][r];
+            Cim[co[e] + r * crow] = c2[e][r];
+          }
         }
       }
       pend = 8 * CNT;
     }
   };
 
-  fetch();
-  if (total > 1) fetch();
-  qk_wait_vm(total > 1 ? 2 : 0);
+#pragma unroll
+  for (int i = 0; i < DEPTH; ++i)
+    if (i < total) fetch();
+  qk_wait_vm(LPS * (min(DEPTH, total) - 1));
   qk_lds_barrier();
   for (int pn = 0; pn < npn; ++pn) {
     for (int pm = 0; pm < npm; ++pm) {
@@ -1378,13 +1434,18 @@ __device__ __forceinline__ void zgemm_ring3(double* __restrict__ Cre, double* __
 }
 
 // the deep kernel's pair loop around the lean GEMM
-template <int OCC, bool RING = false>
-__global__ __launch_bounds__(512, OCC) void qk_sweep_lean_kernel(const SweepArgs g) {
+// MODE 0: lean GEMM (register staging).  MODE 1 (shipped) / 2: ring GEMM, K-tile 8, 3 / 4 slots, 3M product.
+// MODE 4: ring GEMM, K-tile 16, 2 slots (one K-tile in flight), 3M product.  (MODE 3 = 3 slots + four-product MFMA, for a
+// three-workgroups-per-CU build, is not instantiated: at 80 VGPRs it spills into the K loop.)
+//         MODE 5: ring GEMM on 4-wave workgroups (64x32 pass, K-tile 8, 3 slots, 3M), four workgroups per CU.
+template <int OCC, int MODE = 0>
+__global__ __launch_bounds__(MODE == 5 ? 256 : 512, OCC) void qk_sweep_lean_kernel(const SweepArgs g) {
   using G = GemmCfg<64, 16, 8, 64>;
-  constexpr int NW = 8;
+  constexpr int NW = (MODE == 5) ? 4 : 8;
   constexpr bool PROF = false;
   extern __shared__ __attribute__((aligned(16))) double lds[];
-  long long* slot = reinterpret_cast<long long*>(lds + G::LDS_D);
+  constexpr int STAGE_DOUBLES = (MODE == 5) ? 3 * 1536 : (MODE == 1 || MODE == 3) ? 3 * 2048 : G::LDS_D;  // ring slots; lean / 4-slot ring: 64 KiB
+  long long* slot = reinterpret_cast<long long*>(lds + STAGE_DOUBLES);       // then the pair slot and the per-site metadata
   double* Xre = g.scratch + (long long)blockIdx.x * 2 * (g.x_plane + g.t_plane);
   double* Xim = Xre + g.x_plane;
   double* Tre = Xim + g.x_plane;
@@ -1444,9 +1505,13 @@ __global__ __launch_bounds__(512, OCC) void qk_sweep_lean_kernel(const SweepArgs
       const double* Aim = Are + (long long)a * 2 * a2;
       const double* Bre = g.ydata + ldl(m_yo + k);
       const double* Bim = Bre + (long long)b * 2 * b2;
-      if constexpr (RING) {
-        zgemm_ring3<false>(Tre, Tim, 2 * b2, Xre, Xim, a, Bre, Bim, 2 * b2, a, 2 * b2, ldi(m_yt + k), lds);
-        zgemm_ring3<true>(Xre, Xim, a2, Tre, Tim, b2, Are, Aim, a2, b2, a2, 2 * ldi(m_xt + k), lds);
+      if constexpr (MODE != 0) {
+        constexpr int KTL = (MODE == 4) ? 16 : 8;
+        constexpr int NSLOT = (MODE == 2) ? 4 : (MODE == 4) ? 2 : 3;
+        constexpr bool M3 = (MODE != 3);
+        constexpr int PN = (MODE == 5) ? 32 : 64;
+        zgemm_ring3<false, KTL, NSLOT, M3, NW, PN>(Tre, Tim, 2 * b2, Xre, Xim, a, Bre, Bim, 2 * b2, a, 2 * b2, ldi(m_yt + k), lds);
+        zgemm_ring3<true, KTL, NSLOT, M3, NW, PN>(Xre, Xim, a2, Tre, Tim, b2, Are, Aim, a2, b2, a2, 2 * ldi(m_xt + k), lds);
       } else {
         zgemm_lean<false>(Tre, Tim, 2 * b2, Xre, Xim, a, Bre, Bim, 2 * b2, a, 2 * b2, ldi(m_yt + k), lds);
         zgemm_lean<true>(Xre, Xim, a2, Tre, Tim, b2, Are, Aim, a2, b2, a2, 2 * ldi(m_xt + k), lds);
@@ -2139,7 +2204,10 @@ extern "C" int qk_ctx_create(int device_id, qk_ctx** out) {
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(qk_sweep_group_kernel<64, 16, 4, 8, 64>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(qk_sweep_duo_kernel<64, 16, 4, 8, 64>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(qk_sweep_lean_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
-  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(qk_sweep_lean_kernel<4, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(qk_sweep_lean_kernel<4, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(qk_sweep_lean_kernel<4, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(qk_sweep_lean_kernel<4, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(qk_sweep_lean_kernel<4, 5>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(qk_mma_bench_kernel<4, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)GemmCfg<64, 16, 4, 64>::LDS_B));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(qk_mma_bench_kernel<4, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)GemmCfg<64, 16, 4, 64>::LDS_B));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(qk_mma_bench_kernel<4, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)GemmCfg<64, 16, 4, 64>::LDS_B));
@@ -2157,7 +2225,7 @@ extern "C" int qk_ctx_create(int device_id, qk_ctx** out) {
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(qk_mma_bench_kernel<8, 31>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)GemmCfg<64, 16, 4, 64>::LDS_B));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(qk_mma_bench_kernel<8, 63>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)GemmCfg<64, 16, 4, 64>::LDS_B));
   if (const char* v = std::getenv("QK_VARIANT")) c->variant = std::atoi(v);
-  if (const char* v = std::getenv("QK_WGS_PER_CU")) c->wgs_per_cu = std::max(1, std::min(2, std::atoi(v)));
+  if (const char* v = std::getenv("QK_WGS_PER_CU")) c->wgs_per_cu = std::max(1, std::min(4, std::atoi(v)));
   *out = c;
   return QK_OK;
 }
@@ -2382,11 +2450,20 @@ extern "C" int qk_gram_values(qk_ctx* c, const qk_mps_set* xs, const qk_mps_set*
     case 13:  // two-step-deep prefetch, 8 waves (2 tiles per wave, 16 waves per CU)
       qk_sweep_deep_kernel<64, 16, 4, 8, 64><<<dim3(grid), dim3(512), lds_deep, c->stream>>>(a);
       break;
-    case 20:  // ring kernel: LDS-DMA staging ring + 3M complex product
-      qk_sweep_lean_kernel<4, true><<<dim3(grid), dim3(512), lds_deep, c->stream>>>(a);
-      break;
-    default:  // 17: the shipped kernel -- same pipeline with the lean steady-state step
+    case 17:  // lean register-staged sweep (two-step-deep register prefetch, four-product complex MFMA)
       qk_sweep_lean_kernel<4><<<dim3(grid), dim3(512), lds_deep, c->stream>>>(a);
+      break;
+    case 21:  // ring kernel with four slots (three K-tiles in flight)
+      qk_sweep_lean_kernel<4, 2><<<dim3(grid), dim3(512), lds_deep, c->stream>>>(a);
+      break;
+    case 24:  // ring kernel on 4-wave workgroups (64x32 pass), four workgroups per CU (QK_WGS_PER_CU=4)
+      qk_sweep_lean_kernel<4, 5><<<dim3(grid), dim3(256), lds_deep - 28 * 1024, c->stream>>>(a);
+      break;
+    case 23:  // ring kernel, K-tile 16, two slots
+      qk_sweep_lean_kernel<4, 4><<<dim3(grid), dim3(512), lds_deep, c->stream>>>(a);
+      break;
+    default:  // 20: the shipped kernel -- ring sweep: LDS-DMA staging ring (K-tile 8, three slots) + 3M complex product
+      qk_sweep_lean_kernel<4, 1><<<dim3(grid), dim3(512), lds_deep - 16 * 1024, c->stream>>>(a);
       break;
   }
   HIP_TRY(hipGetLastError());
