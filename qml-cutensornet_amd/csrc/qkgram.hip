@@ -1212,6 +1212,12 @@ __device__ __forceinline__ void zgemm_lean(double* __restrict__ Cre, double* __r
 // Staging roles: waves 0-3 bring the re planes, waves 4-7 the im planes; wave w covers K rows
 // 2(w&3), 2(w&3)+1 of both operands (one 1-KiB wave-linear piece of the A plane and one of the B plane).
 // ----------------------------------------------------------------------------------------
+template <int N>
+__device__ __forceinline__ void qk_wait_const() {
+  static_assert(N >= 0 && N < 64, "vmcnt is a 6-bit field");
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
 __device__ __forceinline__ void qk_wait_vm(const int n) {  // wave-uniform n; values above 24 wait for everything
   switch (n) {
     case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
@@ -1389,7 +1395,13 @@ __device__ __forceinline__ void zgemm_ring3(double* __restrict__ Cre, double* __
       if (s + 1 < total) {
         // K-tile s+1 must have landed; everything issued after it may stay in flight: the younger K-tiles and,
         // when it was issued before the previous step's epilogue (DEPTH >= 2), that epilogue's stores
-        qk_wait_vm(LPS * min(DEPTH - 1, total - 2 - s) + (DEPTH >= 2 ? pend : 0));
+        const int young = LPS * min(DEPTH - 1, total - 2 - s);
+        if (DEPTH == 1 || pend == 0) {  // the common case first: the generic switch costs a branch tree per step
+          if (young == LPS * (DEPTH - 1)) qk_wait_const<LPS * (DEPTH - 1)>();
+          else qk_wait_vm(young);
+        } else {
+          qk_wait_vm(young + pend);
+        }
         qk_lds_barrier();
       }
       pend = 0;
