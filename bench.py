@@ -285,7 +285,9 @@ def main():
                 "traffic_source": "profiles/r01/pmc_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, FETCH_SIZE x2 gfx950 correction), bytes per launch" if traffic else None,
                 "kernel_ms": kms,
                 "algorithmic_tflop_per_launch": my["flops"] / 1e12,
-                "executed_padded_tflop_per_launch": my["padded_flops"] / 1e12,
+                # the same count with every bond rounded up to the 16-wide MFMA tile (four-product form); the shipped kernel
+                # issues 3/4 of the K-trimmed part of it (3M complex product): see profiles/r01/pmc_summary.json
+                "padded_4m_tflop_per_launch": my["padded_flops"] / 1e12,
                 "algorithmic_gbytes_per_launch": my["bytes"] / 1e9,
             },
         }
