@@ -40,6 +40,7 @@ CONFIGS = {
 }
 # fp64 matrix peak of MI355X: 256 CU x 4 SIMD x 32 flop/clk (v_mfma_f64_16x16x4: 2048 flop / 64 clk) x 2.4 GHz
 PEAK_F64_MFMA_TFLOPS = 256 * 4 * 32 * 2.4e9 / 1e12
+PEAK_F32_MFMA_TFLOPS = 256 * 4 * 64 * 2.4e9 / 1e12  # v_mfma_f32_16x16x4_f32: 64 flop/clk/SIMD (MI355X_MICROARCH.md)
 
 
 def log(rank, *a):
@@ -144,6 +145,8 @@ def main():
     ap.add_argument("--seed", type=int, default=5)
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU-baseline budget (0 = skip)")
     ap.add_argument("--workers", type=int, default=0, help="host processes for MPS building (0 = all cores / ranks)")
+    ap.add_argument("--precision", default="f64", choices=["f64", "f32"],
+                    help="f64 = the reference's precision and the headline metric; f32 = the complex64 sweep (SURVEY 8f N4), a supplementary line")
     args = ap.parse_args()
     if args.gamma is None:
         args.gamma = 0.1 if args.config == "cfg5" else 1.0
@@ -202,6 +205,15 @@ def main():
     xset = ctx.upload(states)
     upload_s = time.perf_counter() - t0
     info = xset.info()
+    k64_ref = None
+    if args.precision == "f32":  # supplementary line: same workload on fp32 planes, checked against one fp64 Gram (untimed)
+        ref_job = GramJob(ctx, xset, None, world, rank)
+        k64_ref = ref_job.run()
+        ref_job.close()
+        x64 = xset
+        xset = x64.to_f32()
+        x64.close()
+        info = xset.info()
     job = GramJob(ctx, xset, None, world, rank)
     my = job.work[rank]
     log(rank, f"uploaded {info['device_bytes'] / 2**30:.2f} GiB in {upload_s:.1f}s; rank 0 share: {my['pairs']} pairs, {my['flops'] / 1e12:.2f} TFlop algorithmic ({my['padded_flops'] / 1e12:.2f} padded)")
@@ -240,11 +252,12 @@ def main():
     out = None
     if rank == 0:
         achieved = my["flops"] / (kms * 1e-3) / 1e12 if kms > 0 else 0.0
+        peak = PEAK_F64_MFMA_TFLOPS if args.precision == "f64" else PEAK_F32_MFMA_TFLOPS
         # HBM/fabric bytes per launch of the dominant kernel: PMC numbers cannot be collected from inside this
         # process, so the committed rocprofv3 --pmc summary of the SAME workload (profiles/run_rocprof.sh) is quoted.
         traffic = None
         pmc_file = os.path.join(ROOT, "profiles", "r01", "pmc_summary.json")
-        if world == 1 and args.config == "cfg4" and args.gamma == 1.0 and not args.points and args.seed == 5 and os.path.exists(pmc_file):
+        if world == 1 and args.precision == "f64" and args.config == "cfg4" and args.gamma == 1.0 and not args.points and args.seed == 5 and os.path.exists(pmc_file):
             try:
                 traffic = json.load(open(pmc_file))["derived"]["traffic_bytes_per_launch"]
             except (KeyError, ValueError):
@@ -260,7 +273,7 @@ def main():
             "higher_is_better": True,
             "scaling": "strong",
             "vs_baseline": None,
-            "dtype": "f64 (complex128)",
+            "dtype": "f64 (complex128)" if args.precision == "f64" else "f32 (complex64)",
             "data": "synthetic features (normal -> standardise -> MinMax[0,2], seed %d); real ansatz MPS built on the host" % args.seed,
             "config": {
                 "workload": f"{args.config}: {n} qubits x {reps} layers, d={d}, gamma={args.gamma}, truncation 1e-16, {npts}x{npts} symmetric training Gram",
@@ -273,14 +286,15 @@ def main():
                 "mps_build_cpu_s_per_state": binfo["cpu_s_per_state"],
                 "diag_err": diag_err,
                 "sym_err": sym_err,
+                **({"f32_vs_f64_max_abs": float(np.abs(Kh - k64_ref).max()), "f32_vs_f64_median_abs": float(np.median(np.abs(Kh - k64_ref)))} if k64_ref is not None else {}),
             },
             "roofline": {
-                "bound": "mfma",
-                "kernel": "qk_sweep_lean_kernel<4, 1>",
+                "bound": "mfma",  # fp64 matrix cores for f64, fp32 matrix cores for f32
+                "kernel": "qk_sweep_lean_kernel<4, 1>" if args.precision == "f64" else "qk_sweep_ring_kernel<float>",
                 "achieved": achieved,
-                "peak": PEAK_F64_MFMA_TFLOPS,
+                "peak": peak,
                 "unit": "TFLOP/s",
-                "frac": achieved / PEAK_F64_MFMA_TFLOPS,
+                "frac": achieved / peak,
                 "traffic": traffic,
                 "traffic_source": "profiles/r01/pmc_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, FETCH_SIZE x2 gfx950 correction), bytes per launch" if traffic else None,
                 "kernel_ms": kms,
@@ -288,7 +302,7 @@ def main():
                 # the same count with every bond rounded up to the 16-wide MFMA tile (four-product form); the shipped kernel
                 # issues 3/4 of the K-trimmed part of it (3M complex product): see profiles/r01/pmc_summary.json
                 "padded_4m_tflop_per_launch": my["padded_flops"] / 1e12,
-                "algorithmic_gbytes_per_launch": my["bytes"] / 1e9,
+                "algorithmic_gbytes_per_launch": my["bytes"] / 1e9 * (1.0 if args.precision == "f64" else 0.5),
             },
         }
         if world == 1 and args.cpu_seconds > 0:

@@ -92,6 +92,14 @@ int qk_mps_set_destroy(qk_mps_set* set);
 int qk_mps_set_info(const qk_mps_set* set, int32_t* n_states, int32_t* n_sites, int32_t* max_padded_bond,
                     int64_t* device_bytes);
 
+/* Precision of a set's device image: 64 (complex128 planes, what qk_mps_set_create builds) or 32.
+ * qk_mps_set_to_f32 makes a complex64 copy on the device (same layout, same element offsets).  A sweep whose two
+ * sets are fp32 runs on v_mfma_f32_16x16x4_f32 with fp32 X/T scratch; outputs stay double.  The reference never
+ * leaves fp64 (G:141-144 does not set float_precision); this is SURVEY.md section 8f row N4, the fp32-vs-fp64
+ * tolerance sweep its cfg5 asks for.  Mixing an fp32 and an fp64 set in one call is QK_EINVAL.                  */
+int qk_mps_set_precision(const qk_mps_set* set);
+int qk_mps_set_to_f32(qk_ctx* ctx, const qk_mps_set* src, qk_mps_set** out);
+
 /* Host-only packing helper used by qk_mps_set_create (exported so that the
  * packing can be unit-tested without a GPU).  Writes one state's padded planar
  * image; `out` must hold qk_pack_state_size() doubles.                         */

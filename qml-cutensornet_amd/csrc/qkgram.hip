@@ -75,7 +75,8 @@ struct qk_ctx {
 struct qk_mps_set {
   qk_ctx* ctx = nullptr;
   int n_states = 0, n_sites = 0, max_pad = 0;
-  double* d_data = nullptr;
+  int precision = 64;         // bits of a real: 64 (complex128 planes) or 32 (complex64 planes, same element offsets)
+  double* d_data = nullptr;   // the planes; floats when precision == 32
   int32_t* d_dims = nullptr;  // padded bonds [n_states][n_sites+1]
   int32_t* d_true = nullptr;  // true bonds   [n_states][n_sites+1]
   int64_t* d_offs = nullptr;  // re-plane offsets (doubles) [n_states][n_sites]
@@ -1248,35 +1249,54 @@ __device__ __forceinline__ void qk_wait_vm(const int n) {  // wave-uniform n; va
   }
 }
 
+// Scalar traits of the ring GEMM: accumulator vector, MFMA and where an accumulator register lands in the tile.
+typedef float v4f __attribute__((ext_vector_type(4)));
+template <typename T>
+struct QkScalar;
+template <>
+struct QkScalar<double> {
+  using v4 = v4d;
+  static constexpr int ROW_Q = 1, ROW_R = 4;  // v_mfma_f64_16x16x4_f64: register r of lane (q, j) = C[q + 4r][j]
+  static __device__ __forceinline__ v4 mfma(double a, double b, v4 c) { return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0); }
+};
+template <>
+struct QkScalar<float> {
+  using v4 = v4f;
+  static constexpr int ROW_Q = 4, ROW_R = 1;  // v_mfma_f32_16x16x4_f32: register r of lane (q, j) = C[4q + r][j]
+  static __device__ __forceinline__ v4 mfma(float a, float b, v4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+};
+
 // One complex k-step of one tile.  M3: 3M form (three independent accumulators c1 = P1, c2 = P2, c3 = P3);
 // otherwise the plain four-product form (c1 = re, c2 = im, c3 unused).
-template <bool CONJB, bool M3>
-__device__ __forceinline__ void mma3_kstep(v4d& c1, v4d& c2, v4d& c3, const double ar, const double ai, const double br, const double bi) {
+template <bool CONJB, bool M3, typename T>
+__device__ __forceinline__ void mma3_kstep(typename QkScalar<T>::v4& c1, typename QkScalar<T>::v4& c2, typename QkScalar<T>::v4& c3,
+                                           const T ar, const T ai, const T br, const T bi) {
+  using S = QkScalar<T>;
   if constexpr (M3) {
-    const double sa = ar + ai, sb = CONJB ? br - bi : br + bi;
-    c1 = __builtin_amdgcn_mfma_f64_16x16x4f64(ar, br, c1, 0, 0, 0);
-    c2 = __builtin_amdgcn_mfma_f64_16x16x4f64(ai, bi, c2, 0, 0, 0);
-    c3 = __builtin_amdgcn_mfma_f64_16x16x4f64(sa, sb, c3, 0, 0, 0);
+    const T sa = ar + ai, sb = CONJB ? br - bi : br + bi;
+    c1 = S::mfma(ar, br, c1);
+    c2 = S::mfma(ai, bi, c2);
+    c3 = S::mfma(sa, sb, c3);
   } else {
-    const double sbi = CONJB ? -bi : bi;
-    c1 = __builtin_amdgcn_mfma_f64_16x16x4f64(ar, br, c1, 0, 0, 0);
-    c2 = __builtin_amdgcn_mfma_f64_16x16x4f64(ar, sbi, c2, 0, 0, 0);
-    c1 = __builtin_amdgcn_mfma_f64_16x16x4f64(-ai, sbi, c1, 0, 0, 0);
-    c2 = __builtin_amdgcn_mfma_f64_16x16x4f64(ai, br, c2, 0, 0, 0);
+    const T sbi = CONJB ? -bi : bi;
+    c1 = S::mfma(ar, br, c1);
+    c2 = S::mfma(ar, sbi, c2);
+    c1 = S::mfma(-ai, sbi, c1);
+    c2 = S::mfma(ai, br, c2);
   }
 }
 
-template <bool CONJB, int CNT, bool FULLK, bool M3, int KTL, int PN = 64>
-__device__ __forceinline__ void mma_ring3(v4d (&c1)[2], v4d (&c2)[2], v4d (&c3)[2], const int (&la)[2], const int (&lb)[2],
-                                          const double* __restrict__ base, const int ksteps) {
+template <bool CONJB, int CNT, bool FULLK, bool M3, int KTL, int PN = 64, typename T = double>
+__device__ __forceinline__ void mma_ring3(typename QkScalar<T>::v4 (&c1)[2], typename QkScalar<T>::v4 (&c2)[2], typename QkScalar<T>::v4 (&c3)[2],
+                                          const int (&la)[2], const int (&lb)[2], const T* __restrict__ base, const int ksteps) {
   constexpr int PM = 64, APL = KTL * PM, BPL = KTL * PN, KS = KTL / 4;  // staged planes: A re | A im | B re | B im
   if constexpr (CNT == 0) return;
   if constexpr (FULLK) {
-    double far[2], fai[2], fbr[2], fbi[2];
+    T far[2], fai[2], fbr[2], fbi[2];
     auto load = [&](int g, int buf) __attribute__((always_inline)) {
       const int e = g / KS, ks = g % KS;
-      const double* pa = base + la[e] + 4 * ks * PM;
-      const double* pb = base + lb[e] + 4 * ks * PN;
+      const T* pa = base + la[e] + 4 * ks * PM;
+      const T* pb = base + lb[e] + 4 * ks * PN;
       far[buf] = pa[0];
       fai[buf] = pa[APL];
       fbr[buf] = pb[0];
@@ -1288,7 +1308,7 @@ __device__ __forceinline__ void mma_ring3(v4d (&c1)[2], v4d (&c2)[2], v4d (&c3)[
       const int e = g / KS;
       if (g + 1 < KS * CNT) load(g + 1, (g + 1) & 1);
       __builtin_amdgcn_sched_barrier(0);
-      mma3_kstep<CONJB, M3>(c1[e], c2[e], c3[e], far[g & 1], fai[g & 1], fbr[g & 1], fbi[g & 1]);
+      mma3_kstep<CONJB, M3, T>(c1[e], c2[e], c3[e], far[g & 1], fai[g & 1], fbr[g & 1], fbi[g & 1]);
       __builtin_amdgcn_sched_barrier(0);
     }
   } else {  // the last K-tile of a K range that does not fill it: ksteps in 1..KS-1
@@ -1297,25 +1317,31 @@ __device__ __forceinline__ void mma_ring3(v4d (&c1)[2], v4d (&c2)[2], v4d (&c3)[
 #pragma unroll
       for (int ks = 0; ks < KS - 1; ++ks) {
         if (ks < ksteps) {
-          const double* pa = base + la[e] + 4 * ks * PM;
-          const double* pb = base + lb[e] + 4 * ks * PN;
-          mma3_kstep<CONJB, M3>(c1[e], c2[e], c3[e], pa[0], pa[APL], pb[0], pb[BPL]);
+          const T* pa = base + la[e] + 4 * ks * PM;
+          const T* pb = base + lb[e] + 4 * ks * PN;
+          mma3_kstep<CONJB, M3, T>(c1[e], c2[e], c3[e], pa[0], pa[APL], pb[0], pb[BPL]);
         }
       }
     }
   }
 }
 
-template <bool CONJB, int KTL, int NSLOT, bool M3, int NW = 8, int PN = 64>
-__device__ __forceinline__ void zgemm_ring3(double* __restrict__ Cre, double* __restrict__ Cim, const int ldc,
-                                            const double* __restrict__ Are, const double* __restrict__ Aim, const int lda,
-                                            const double* __restrict__ Bre, const double* __restrict__ Bim, const int ldb,
-                                            const int M, const int N, const int Ktrue, double* __restrict__ lds) {
-  static_assert((NW == 8 && PN == 64) || (NW == 4 && PN == 32 && KTL == 8), "supported shapes");
+template <bool CONJB, int KTL, int NSLOT, bool M3, int NW = 8, int PN = 64, typename T = double>
+__device__ __forceinline__ void zgemm_ring3(T* __restrict__ Cre, T* __restrict__ Cim, const int ldc,
+                                            const T* __restrict__ Are, const T* __restrict__ Aim, const int lda,
+                                            const T* __restrict__ Bre, const T* __restrict__ Bim, const int ldb,
+                                            const int M, const int N, const int Ktrue, T* __restrict__ lds) {
+  using S = QkScalar<T>;
+  using V4 = typename S::v4;
+  constexpr int EPL = 16 / (int)sizeof(T);            // elements per lane and LDS-DMA (2 doubles / 4 floats)
+  constexpr int CHUNK = 1024 / (int)sizeof(T);        // elements per 1-KiB wave-linear piece
+  constexpr int RPC = CHUNK / 64;                     // K rows of a 64-wide plane per piece (2 / 4)
+  constexpr bool SPLIT = (KTL == 4 * RPC);            // planes of four pieces: waves 0-3 take re, waves 4-7 im
+  static_assert((NW == 8 && PN == 64 && (KTL == 4 * RPC || KTL == 8 * RPC)) || (NW == 4 && PN == 32 && KTL == 8 && sizeof(T) == 8), "supported shapes");
   constexpr int PM = 64;
   constexpr int APL = KTL * PM, BPL = KTL * PN, SLOT_D = 2 * APL + 2 * BPL;  // doubles per plane / per ring slot
   constexpr int DEPTH = NSLOT - 1;                 // K-tiles in flight ahead of the one being multiplied
-  constexpr int LPS = (NW == 4) ? 3 : KTL / 4;     // LDS-DMA instructions per wave and K-tile
+  constexpr int LPS = (NW == 4) ? 3 : (SPLIT ? 2 : 4);  // LDS-DMA instructions per wave and K-tile
   typedef __attribute__((address_space(3))) void* lds_ptr_t;
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -1332,49 +1358,50 @@ __device__ __forceinline__ void zgemm_ring3(double* __restrict__ Cre, double* __
   // 8 waves, K-tile 16: every wave brings rows 2w, 2w+1 of all four planes.
   // 4 waves (64x32 pass), K-tile 8: wave w brings rows 2w, 2w+1 of A re and A im, and one of the four 1-KiB pieces
   // of the B planes (plane w>>1, K rows 4(w&1) .. +3; a B row is 32 doubles).
-  const int w3 = (NW == 8 && KTL == 8) ? (wave & 3) : wave;
-  const int pl = (NW == 8 && KTL == 8) ? (wave >> 2) : 0;
+  const int w3 = (NW == 8 && SPLIT) ? (wave & 3) : wave;
+  const int pl = (NW == 8 && SPLIT) ? (wave >> 2) : 0;
   const long long a_im = Aim - Are, b_im = Bim - Bre;  // plane strides of the operands
-  const double* const Asrc = pl ? Aim : Are;
-  const double* const Bsrc = (NW == 4) ? ((wave >> 1) ? Bim : Bre) : (pl ? Bim : Bre);
-  const int srow = 2 * w3 + (lane >> 5), scol = (lane & 31) * 2;
+  const T* const Asrc = pl ? Aim : Are;
+  const T* const Bsrc = (NW == 4) ? ((wave >> 1) ? Bim : Bre) : (pl ? Bim : Bre);
+  constexpr int LPR = 64 / RPC;                        // lanes per 64-wide K row of a piece
+  const int srow = RPC * w3 + lane / LPR, scol = (lane % LPR) * EPL;
   const int srowB = (NW == 4) ? 4 * (wave & 1) + (lane >> 4) : srow;
   const int scolB = (NW == 4) ? (lane & 15) * 2 : scol;
   const unsigned rA = (unsigned)(srow * lda), rB = (unsigned)(srowB * ldb);
-  double* const dA = lds + pl * APL + w3 * 128;        // slot 0 destinations (wave-uniform)
-  double* const dB = (NW == 4) ? lds + 2 * APL + (wave >> 1) * BPL + (wave & 1) * 128 : lds + 2 * APL + pl * BPL + w3 * 128;
+  T* const dA = lds + pl * APL + w3 * CHUNK;           // slot 0 destinations (wave-uniform)
+  T* const dB = (NW == 4) ? lds + 2 * APL + (wave >> 1) * BPL + (wave & 1) * CHUNK : lds + 2 * APL + pl * BPL + w3 * CHUNK;
 
   // ---- fetch-side pass state (runs DEPTH K-tiles ahead of the compute side, across pass boundaries)
   int f_pm = 0, f_pn = 0, f_left = nk, f_slot = 0;
-  const double *fa = Asrc, *fb = Bsrc;
-  unsigned offA = rA + (unsigned)min(scol, min(PM, M) - 2), offB = rB + (unsigned)min(scolB, min(PN, N) - 2);
+  const T *fa = Asrc, *fb = Bsrc;
+  unsigned offA = rA + (unsigned)min(scol, min(PM, M) - EPL), offB = rB + (unsigned)min(scolB, min(PN, N) - EPL);
   auto fetch = [&]() __attribute__((always_inline)) {
     __builtin_amdgcn_global_load_lds(fa + offA, (lds_ptr_t)(dA + f_slot), 16, 0, 0);
-    if constexpr (KTL == 16 || NW == 4) __builtin_amdgcn_global_load_lds(fa + a_im + offA, (lds_ptr_t)(dA + APL + f_slot), 16, 0, 0);
+    if constexpr (!SPLIT || NW == 4) __builtin_amdgcn_global_load_lds(fa + a_im + offA, (lds_ptr_t)(dA + APL + f_slot), 16, 0, 0);
     __builtin_amdgcn_global_load_lds(fb + offB, (lds_ptr_t)(dB + f_slot), 16, 0, 0);
-    if constexpr (KTL == 16) __builtin_amdgcn_global_load_lds(fb + b_im + offB, (lds_ptr_t)(dB + BPL + f_slot), 16, 0, 0);
+    if constexpr (!SPLIT && NW == 8) __builtin_amdgcn_global_load_lds(fb + b_im + offB, (lds_ptr_t)(dB + BPL + f_slot), 16, 0, 0);
     fa += sA, fb += sB;
     f_slot = (f_slot == (NSLOT - 1) * SLOT_D) ? 0 : f_slot + SLOT_D;
     if (--f_left == 0) {
       if (++f_pm == npm) f_pm = 0, ++f_pn;
       const int m0 = f_pm * PM, n0 = f_pn * PN;
       fa = Asrc + m0, fb = Bsrc + n0;
-      offA = rA + (unsigned)min(scol, min(PM, M - m0) - 2);
-      offB = rB + (unsigned)min(scolB, min(PN, N - n0) - 2);
+      offA = rA + (unsigned)min(scol, min(PM, M - m0) - EPL);
+      offB = rB + (unsigned)min(scolB, min(PN, N - n0) - EPL);
       f_left = nk;
     }
   };
 
   // ---- step counters shared by all passes
   int s = 0, c_slot = 0, pend = 0;
-  const int crow = 4 * ldc;
+  const int crow = S::ROW_R * ldc;
 
   // One pass = nk steps on one 64x64 output tile, specialised on the number of tiles this wave owns so that
   // the MFMA block is branch-free and the accumulators live only inside the pass.
   auto run_pass = [&](auto cnt_tag, const int m0, const int n0, const int mt, const int vt) __attribute__((always_inline)) {
     constexpr int CNT = decltype(cnt_tag)::value;
     int la[2], lb[2], co[2];
-    v4d c1[2], c2[2], c3[2];
+    V4 c1[2], c2[2], c3[2];
     const int inv = (mt == 1) ? 32 : (mt == 2) ? 16 : (mt == 3) ? 11 : 8;  // t / mt == (t * inv) >> 5 for t < 16
 #pragma unroll
     for (int e = 0; e < 2; ++e) {
@@ -1382,16 +1409,16 @@ __device__ __forceinline__ void zgemm_ring3(double* __restrict__ Cre, double* __
       const int tn = (t * inv) >> 5, tm = t - tn * mt;
       la[e] = q * PM + tm * TILE + j;
       lb[e] = 2 * APL + q * PN + tn * TILE + j;
-      co[e] = (m0 + tm * TILE + q) * ldc + n0 + tn * TILE + j;
-      c1[e] = (v4d){0, 0, 0, 0};
-      c2[e] = (v4d){0, 0, 0, 0};
-      c3[e] = (v4d){0, 0, 0, 0};
+      co[e] = (m0 + tm * TILE + S::ROW_Q * q) * ldc + n0 + tn * TILE + j;
+      c1[e] = (V4){0, 0, 0, 0};
+      c2[e] = (V4){0, 0, 0, 0};
+      c3[e] = (V4){0, 0, 0, 0};
     }
     for (int kt = 0; kt < nk; ++kt, ++s) {  // (ring)
       if (s + DEPTH < total) fetch();                    // K-tile s+DEPTH -> the slot read in step s-1
-      const double* base = lds + c_slot;
-      if (kt + 1 < nk || ks_last == KTL / 4) mma_ring3<CONJB, CNT, true, M3, KTL, PN>(c1, c2, c3, la, lb, base, KTL / 4);
-      else mma_ring3<CONJB, CNT, false, M3, KTL, PN>(c1, c2, c3, la, lb, base, ks_last);
+      const T* base = lds + c_slot;
+      if (kt + 1 < nk || ks_last == KTL / 4) mma_ring3<CONJB, CNT, true, M3, KTL, PN, T>(c1, c2, c3, la, lb, base, KTL / 4);
+      else mma_ring3<CONJB, CNT, false, M3, KTL, PN, T>(c1, c2, c3, la, lb, base, ks_last);
       if (s + 1 < total) {
         // K-tile s+1 must have landed; everything issued after it may stay in flight: the younger K-tiles and,
         // when it was issued before the previous step's epilogue (DEPTH >= 2), that epilogue's stores
@@ -1413,7 +1440,7 @@ __device__ __forceinline__ void zgemm_ring3(double* __restrict__ Cre, double* __
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           if constexpr (M3) {
-            const double p1 = c1[e][r], p2 = c2[e][r], p3 = c3[e][r];
+            const T p1 = c1[e][r], p2 = c2[e][r], p3 = c3[e][r];
             Cre[co[e] + r * crow] = CONJB ? p1 + p2 : p1 - p2;
             Cim[co[e] + r * crow] = CONJB ? (p3 - p1) + p2 : (p3 - p1) - p2;
           } else {
@@ -1546,6 +1573,94 @@ __global__ __launch_bounds__(MODE == 5 ? 256 : 512, OCC) void qk_sweep_lean_kern
   }
 }
 
+
+// ----------------------------------------------------------------------------------------
+// The ring sweep as its own kernel, templated on the scalar type:
+//   T = double: the same code path as qk_sweep_lean_kernel<4, 1> (K-tile 8);
+//   T = float : complex64 sweep on v_mfma_f32_16x16x4_f32 (K-tile 16: the same 16-KiB slots, pieces and roles).
+// The MPS set is read as T planes with the SAME element offsets as the fp64 image (qk_mps_set_to_f32 converts
+// element by element), the X/T scratch holds T, the outputs are doubles.
+// ----------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(512, 4) void qk_sweep_ring_kernel(const SweepArgs g) {
+  constexpr int NW = 8;
+  constexpr int KTL = 32 / (int)sizeof(T) * 2;  // 8 rows of doubles, 16 rows of floats: 16-KiB slots either way
+  constexpr int SLOT_BYTES = 16 * 1024, NSLOT = 3;
+  extern __shared__ __attribute__((aligned(16))) double lds_raw[];
+  T* lds = reinterpret_cast<T*>(lds_raw);
+  long long* slot = reinterpret_cast<long long*>(reinterpret_cast<char*>(lds_raw) + NSLOT * SLOT_BYTES);
+  const T* xdata = reinterpret_cast<const T*>(g.xdata);
+  const T* ydata = reinterpret_cast<const T*>(g.ydata);
+  T* Xre = reinterpret_cast<T*>(g.scratch) + (long long)blockIdx.x * 2 * (g.x_plane + g.t_plane);
+  T* Xim = Xre + g.x_plane;
+  T* Tre = Xim + g.x_plane;
+  T* Tim = Tre + g.t_plane;
+  const int tid = threadIdx.x;
+  for (;;) {
+    if (tid == 0) *slot = (long long)atomicAdd(g.counter, 1ull);
+    __syncthreads();
+    const long long p = *slot;
+    __syncthreads();
+    if (p >= g.npairs) break;
+    const int xi = g.pairs[2 * p], yj = g.pairs[2 * p + 1];
+    // per-site metadata of the pair, staged once: [xd | yd | xt | yt] (n+1 ints each) then [xo | yo] (n int64)
+    const int n1 = g.n_sites + 1;
+    int* m_xd = reinterpret_cast<int*>(slot + 2);
+    int* m_yd = m_xd + n1;
+    int* m_xt = m_yd + n1;
+    int* m_yt = m_xt + n1;
+    long long* m_xo = reinterpret_cast<long long*>(m_xd + 4 * n1 + (4 * n1 & 1));
+    long long* m_yo = m_xo + g.n_sites;
+    for (int e = tid; e < n1; e += 64 * NW) {
+      m_xd[e] = g.xdims[(long long)xi * n1 + e];
+      m_yd[e] = g.ydims[(long long)yj * n1 + e];
+      m_xt[e] = g.xtrue[(long long)xi * n1 + e];
+      m_yt[e] = g.ytrue[(long long)yj * n1 + e];
+      if (e < g.n_sites) {
+        m_xo[e] = g.xoffs[(long long)xi * g.n_sites + e];
+        m_yo[e] = g.yoffs[(long long)yj * g.n_sites + e];
+      }
+    }
+    __syncthreads();
+    auto ldi = [&](const int* q_) __attribute__((always_inline)) { return __builtin_amdgcn_readfirstlane(*q_); };
+    auto ldl = [&](const long long* q_) __attribute__((always_inline)) {
+      const long long v = *q_;
+      const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v);
+      const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)((unsigned long long)v >> 32));
+      return (long long)(((unsigned long long)hi << 32) | lo);
+    };
+    {
+      const int a = ldi(m_xd), b = ldi(m_yd);
+      for (int e = tid; e < a * b; e += 64 * NW) {
+        Xre[e] = (e == 0) ? (T)1 : (T)0;
+        Xim[e] = (T)0;
+      }
+      __syncthreads();
+    }
+    for (int k = 0; k < g.n_sites; ++k) {
+      const int a = ldi(m_xd + k), a2 = ldi(m_xd + k + 1), b = ldi(m_yd + k), b2 = ldi(m_yd + k + 1);
+      const T* Are = xdata + ldl(m_xo + k);
+      const T* Aim = Are + (long long)a * 2 * a2;
+      const T* Bre = ydata + ldl(m_yo + k);
+      const T* Bim = Bre + (long long)b * 2 * b2;
+      zgemm_ring3<false, KTL, NSLOT, true, NW, 64>(Tre, Tim, 2 * b2, Xre, Xim, a, Bre, Bim, 2 * b2, a, 2 * b2, ldi(m_yt + k), lds);
+      zgemm_ring3<true, KTL, NSLOT, true, NW, 64>(Xre, Xim, a2, Tre, Tim, b2, Are, Aim, a2, b2, a2, 2 * ldi(m_xt + k), lds);
+    }
+    if (tid == 0) {
+      const double re = (double)Xre[0], im = (double)Xim[0];
+      g.values[p] = re * re + im * im;
+      if (g.z) {
+        g.z[2 * p] = re;
+        g.z[2 * p + 1] = im;
+      }
+    }
+    __syncthreads();
+  }
+}
+
+__global__ void qk_convert_f32_kernel(const double* __restrict__ src, float* __restrict__ dst, const long long n) {
+  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long long)gridDim.x * blockDim.x) dst[e] = (float)src[e];
+}
 
 // ----------------------------------------------------------------------------------------
 // v4: group sweep.  One workgroup carries up to GMAX pairs that share the x state through the
@@ -2167,6 +2282,13 @@ __global__ void qk_scatter_kernel(const int32_t* __restrict__ pairs, const doubl
 }
 
 // self-test: C[16x16] = sum_{k<16} P[k][m] * Q[k][n] with the fragment maps used above
+__global__ void qk_selftest_f32_kernel(const float* __restrict__ P, const float* __restrict__ Q, float* __restrict__ C) {
+  const int lane = threadIdx.x & 63, j = lane & 15, q = lane >> 4;
+  v4f acc = {0, 0, 0, 0};
+  for (int ks = 0; ks < 4; ++ks) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(P[(4 * ks + q) * 16 + j], Q[(4 * ks + q) * 16 + j], acc, 0, 0, 0);
+  for (int r = 0; r < 4; ++r) C[(4 * q + r) * 16 + j] = acc[r];
+}
+
 __global__ void qk_selftest_kernel(const double* __restrict__ P, const double* __restrict__ Q, double* __restrict__ C) {
   const int lane = threadIdx.x & 63, j = lane & 15, q = lane >> 4;
   v4d acc = {0, 0, 0, 0};
@@ -2220,6 +2342,7 @@ extern "C" int qk_ctx_create(int device_id, qk_ctx** out) {
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(qk_sweep_lean_kernel<4, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(qk_sweep_lean_kernel<4, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(qk_sweep_lean_kernel<4, 5>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(qk_sweep_ring_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(qk_mma_bench_kernel<4, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)GemmCfg<64, 16, 4, 64>::LDS_B));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(qk_mma_bench_kernel<4, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)GemmCfg<64, 16, 4, 64>::LDS_B));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(qk_mma_bench_kernel<4, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)GemmCfg<64, 16, 4, 64>::LDS_B));
@@ -2355,6 +2478,40 @@ extern "C" int qk_mps_set_info(const qk_mps_set* m, int32_t* n_states, int32_t* 
   return QK_OK;
 }
 
+extern "C" int qk_mps_set_precision(const qk_mps_set* m) { return m ? m->precision : 0; }
+
+extern "C" int qk_mps_set_to_f32(qk_ctx* c, const qk_mps_set* src, qk_mps_set** out) {
+  if (!c || !src || !out) return fail(QK_EINVAL, "qk_mps_set_to_f32: null argument");
+  if (src->ctx != c) return fail(QK_EINVAL, "qk_mps_set_to_f32: the set belongs to another context");
+  if (src->precision != 64) return fail(QK_EINVAL, "qk_mps_set_to_f32: the source set is not fp64");
+  HIP_TRY(hipSetDevice(c->device));
+  qk_mps_set* m = new (std::nothrow) qk_mps_set;
+  if (!m) return fail(QK_ENOMEM, "qk_mps_set_to_f32: out of memory");
+  m->ctx = c, m->n_states = src->n_states, m->n_sites = src->n_sites, m->max_pad = src->max_pad, m->precision = 32;
+  m->dims_true = src->dims_true;
+  const long long n = src->bytes / (long long)sizeof(double);
+  m->bytes = n * (long long)sizeof(float);
+  const size_t nd = (size_t)src->n_states * (src->n_sites + 1), no = (size_t)src->n_states * src->n_sites;
+  hipError_t e = hipMalloc(&m->d_data, (size_t)m->bytes);
+  if (e == hipSuccess) e = hipMalloc(&m->d_dims, nd * sizeof(int32_t));
+  if (e == hipSuccess) e = hipMalloc(&m->d_true, nd * sizeof(int32_t));
+  if (e == hipSuccess) e = hipMalloc(&m->d_offs, no * sizeof(int64_t));
+  if (e == hipSuccess) e = hipMemcpyAsync(m->d_dims, src->d_dims, nd * sizeof(int32_t), hipMemcpyDeviceToDevice, c->stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(m->d_true, src->d_true, nd * sizeof(int32_t), hipMemcpyDeviceToDevice, c->stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(m->d_offs, src->d_offs, no * sizeof(int64_t), hipMemcpyDeviceToDevice, c->stream);
+  if (e == hipSuccess) {
+    qk_convert_f32_kernel<<<dim3(4 * c->num_cus), dim3(256), 0, c->stream>>>(src->d_data, reinterpret_cast<float*>(m->d_data), n);
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+  if (e != hipSuccess) {
+    qk_mps_set_destroy(m);
+    return fail(QK_EDEVICE, "qk_mps_set_to_f32: %s", hipGetErrorString(e));
+  }
+  *out = m;
+  return QK_OK;
+}
+
 static int ensure_plan_uploaded(qk_ctx* c, qk_plan* p) {
   if (p->d_pairs && p->up_ctx == c) return QK_OK;
   if (p->d_pairs) {
@@ -2391,8 +2548,11 @@ extern "C" int qk_gram_values(qk_ctx* c, const qk_mps_set* xs, const qk_mps_set*
   int rc = ensure_plan_uploaded(c, plan);
   if (rc != QK_OK) return rc;
 
-  const bool grouped = (c->variant == 14);
-  const bool duo = (c->variant == 16);
+  if (xs->precision != ys->precision) return fail(QK_EINVAL, "qk_gram_values: the two sets differ in precision (fp%d, fp%d)", xs->precision, ys->precision);
+  const bool f32 = (xs->precision == 32);
+  if (f32) c->last.bytes *= 0.5;  // complex64 planes
+  const bool grouped = (c->variant == 14) && !f32;
+  const bool duo = (c->variant == 16) && !f32;
   const long long members = grouped ? GMAX : 1;  // pairs stacked in one X/T buffer
   const long long chains = duo ? 2 : 1;          // independent X/T buffer sets per workgroup
   const long long x_plane = members * xs->max_pad * ys->max_pad;
@@ -2427,6 +2587,9 @@ extern "C" int qk_gram_values(qk_ctx* c, const qk_mps_set* xs, const qk_mps_set*
   // deep kernels also keep the pair's per-site metadata in LDS: 4 (n+1) ints + 2 n int64 (+ alignment)
   const size_t lds_deep = lds_b + 16 + (size_t)(4 * (xs->n_sites + 1) + 2) * sizeof(int) + (size_t)2 * xs->n_sites * sizeof(long long);
   if (lds_deep > 80 * 1024) return fail(QK_EINVAL, "qk_gram_values: %d sites need %zu bytes of LDS per workgroup (limit 80 KiB for 2 workgroups per CU)", xs->n_sites, lds_deep);
+  if (f32) {  // complex64 sweep: the ring kernel on fp32 planes; QK_VARIANT does not apply
+    qk_sweep_ring_kernel<float><<<dim3(grid), dim3(512), lds_deep - 16 * 1024, c->stream>>>(a);
+  } else
   switch (c->variant) {
     case 0:  // v1: per-pass pipeline, 4 waves
       qk_sweep_kernel<<<dim3(grid), dim3(WG_THREADS), LDS_BYTES, c->stream>>>(a);
@@ -2683,5 +2846,22 @@ extern "C" int qk_selftest_mfma(qk_ctx* c) {
   double worst = 0;
   for (int e = 0; e < 256; ++e) worst = std::max(worst, std::fabs(hc[e] - ref[e]));
   if (worst > 1e-9) return fail(QK_EDEVICE, "qk_selftest_mfma: f64 MFMA fragment map mismatch (max abs error %.3g)", worst);
+  // the same product through v_mfma_f32_16x16x4_f32 (operands are exact in fp32; sums of 16 such products too)
+  float fp[256], fq[256], fc[256];
+  for (int e = 0; e < 256; ++e) fp[e] = (float)hp[e], fq[e] = (float)hq[e];
+  float *ep, *eq, *ec;
+  HIP_TRY(hipMalloc(&ep, sizeof fp));
+  HIP_TRY(hipMalloc(&eq, sizeof fq));
+  HIP_TRY(hipMalloc(&ec, sizeof fc));
+  HIP_TRY(hipMemcpy(ep, fp, sizeof fp, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(eq, fq, sizeof fq, hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(qk_selftest_f32_kernel, dim3(1), dim3(64), 0, c->stream, ep, eq, ec);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  HIP_TRY(hipMemcpy(fc, ec, sizeof fc, hipMemcpyDeviceToHost));
+  (void)hipFree(ep), (void)hipFree(eq), (void)hipFree(ec);
+  worst = 0;
+  for (int e = 0; e < 256; ++e) worst = std::max(worst, std::fabs((double)fc[e] - ref[e]));
+  if (worst > 1e-3) return fail(QK_EDEVICE, "qk_selftest_mfma: f32 MFMA fragment map mismatch (max abs error %.3g)", worst);
   return QK_OK;
 }

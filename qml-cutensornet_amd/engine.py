@@ -53,6 +53,8 @@ _SIGNATURES = [
     ("qk_mps_set_create", C.c_int, [_P, C.c_int32, C.c_int32, _P, _P, C.c_int32, C.POINTER(_P)]),
     ("qk_mps_set_destroy", C.c_int, [_P]),
     ("qk_mps_set_info", C.c_int, [_P, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int64)]),
+    ("qk_mps_set_precision", C.c_int, [_P]),
+    ("qk_mps_set_to_f32", C.c_int, [_P, _P, C.POINTER(_P)]),
     ("qk_pack_state_size", C.c_int64, [C.c_int32, _P]),
     ("qk_pack_state", C.c_int, [C.c_int32, _P, _P, C.c_int32, _P, _P]),
     ("qk_plan_create", C.c_int, [C.c_int32, C.c_int32, _P, C.c_int32, _P, C.c_uint32, C.c_int32, C.c_int32, C.c_int32, C.POINTER(_P)]),
@@ -219,6 +221,18 @@ class MpsSet:
         a, b, c, d = C.c_int32(), C.c_int32(), C.c_int32(), C.c_int64()
         _check(lib().qk_mps_set_info(self._h, C.byref(a), C.byref(b), C.byref(c), C.byref(d)), "qk_mps_set_info")
         return {"n_states": a.value, "n_sites": b.value, "max_padded_bond": c.value, "device_bytes": d.value}
+
+    @property
+    def precision(self) -> int:
+        """Bits of a real of the device image: 64 (complex128) or 32 (complex64)."""
+        return int(lib().qk_mps_set_precision(self._h))
+
+    def to_f32(self) -> "MpsSet":
+        """A complex64 copy of this set on the same device; sweeps over fp32 sets run the
+        fp32-MFMA kernel.  Both sets of a Gram must have the same precision."""
+        h = _P()
+        _check(lib().qk_mps_set_to_f32(self.ctx.handle, self._h, C.byref(h)), "qk_mps_set_to_f32")
+        return MpsSet(self.ctx, h, self.dims)
 
     def close(self):
         if self._h:

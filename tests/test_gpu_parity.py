@@ -298,3 +298,43 @@ def test_bad_inputs_fail_loudly(gpu_ctx):
             gpu_ctx.gram(da, db)
     with pytest.raises(RuntimeError):
         a.vdot(b)
+
+
+# ------------------------------------------------------------------ N4: complex64 sweep (fp32 MFMA)
+F32_TOL = 2e-5  # |z32 - z64| on |z| <= 1 quantities; measured 1e-7 ... 3e-6 (profiles/r01/fp32_tolerance.txt)
+
+
+@pytest.mark.parametrize("n,chi_max,nx,ny,seed", [(6, 4, 3, 2, 1), (14, 40, 4, 5, 3), (18, 150, 2, 3, 5), (40, 70, 3, 3, 7)])
+def test_f32_sweep_close_to_f64(gpu_ctx, n, chi_max, nx, ny, seed):
+    import qml_cutensornet_amd as Q
+    from oracle import restatement as R
+
+    rng = np.random.default_rng(seed)
+    xs = [Q.random_mps(n, _ragged_profile(rng, n, chi_max), rng) for _ in range(nx)]
+    ys = [Q.random_mps(n, _ragged_profile(rng, n, chi_max), rng) for _ in range(ny)]
+    z_ref = np.array([[R.mps_inner(x.tensors, y.tensors) for x in xs] for y in ys])
+    with gpu_ctx.upload(xs) as dx, gpu_ctx.upload(ys) as dy, dx.to_f32() as fx, dy.to_f32() as fy:
+        assert dx.precision == 64 and fx.precision == 32
+        assert fx.info()["device_bytes"] * 2 == dx.info()["device_bytes"]
+        z32 = gpu_ctx.overlaps(fx, fy)
+        K32 = gpu_ctx.gram(fx, fy)
+        with pytest.raises(Exception):  # mixed precision is refused, loudly
+            gpu_ctx.overlaps(fx, dy)
+    assert np.abs(z32 - z_ref).max() < F32_TOL
+    assert np.abs(K32 - np.abs(z_ref) ** 2).max() < F32_TOL
+    assert np.abs(z32 - z_ref).max() > 0  # it really is a different arithmetic
+
+
+def test_f32_gram_of_ansatz_states(gpu_ctx):
+    import qml_cutensornet_amd as Q
+    from oracle import restatement as R
+
+    X = R.synthetic_features(10, 16, 5)
+    ans = Q.KernelStateAnsatz(16, 3, 1.0, Q.entanglement_graph(16, 2))
+    states = [Q.simulate(ans.circuit_for_data(x), 1 - 1e-16) for x in X]
+    with gpu_ctx.upload(states) as dx, dx.to_f32() as fx:
+        K64 = gpu_ctx.gram(dx)
+        K32 = gpu_ctx.gram(fx)
+    assert np.abs(K32 - K64).max() < F32_TOL
+    assert np.abs(np.diag(K32) - 1).max() < F32_TOL
+    assert np.abs(K32 - K32.T).max() == 0.0
