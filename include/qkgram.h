@@ -108,10 +108,11 @@ int qk_pack_state(int32_t n_sites, const int32_t* bond_dims, const double* const
                   double* out, int64_t* site_offsets /* [n_sites] offsets of each re-plane, in doubles */);
 
 /* ---- plans (host side; no GPU needed) ---------------------------------------
- * Enumerate the pairs of the Gram, order them for cache locality (tiles of
- * `block` x `block` states) and, inside a tile, by decreasing estimated cost,
- * then deal them round-robin to `world_size` ranks and keep rank `rank`'s
- * share.  x_dims / y_dims are the bond_dims tables of the two sets
+ * Enumerate the pairs of the Gram in tiles of `block` x `block` states (block <= 0:
+ * one tile = the whole Gram), sort each tile by decreasing estimated cost, deal the
+ * pairs to `world_size` ranks in serpentine order (0..W-1, W-1..0, ...: equal counts
+ * +-1 and flops within a fraction of a percent) and keep rank `rank`'s share, itself
+ * ordered heaviest first for the device-side work queue.  x_dims / y_dims are the bond_dims tables of the two sets
  * (y_dims = NULL with QK_PLAN_SYMMETRIC).  Pairs are (x index i, y index j);
  * the Gram entry is K[j][i]  (rows = Y, cols = X: G:387, J:106).               */
 int qk_plan_create(int32_t n_sites, int32_t nx, const int32_t* x_dims, int32_t ny, const int32_t* y_dims,

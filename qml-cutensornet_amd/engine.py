@@ -144,7 +144,7 @@ def pack_state(mps, layout=QK_LAYOUT_LPR):
 class Plan:
     """Ordered share of the Gram's (x, y) pairs for one rank (host object)."""
 
-    def __init__(self, x_dims, y_dims=None, world_size=1, rank=0, block=16):
+    def __init__(self, x_dims, y_dims=None, world_size=1, rank=0, block=0):
         L = lib()
         xd = np.ascontiguousarray(x_dims, dtype=np.int32)
         self.symmetric = y_dims is None

@@ -26,7 +26,7 @@ class GramJob:
         if block is None:
             import os
 
-            block = int(os.environ.get("QK_PLAN_BLOCK", "16"))
+            block = int(os.environ.get("QK_PLAN_BLOCK", "0"))  # 0 = no locality tiles: one global cost order
         self.nx = len(xset)
         self.ny = self.nx if self.symmetric else len(yset)
         ydims = None if self.symmetric else yset.dims
