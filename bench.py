@@ -290,7 +290,7 @@ def main():
             },
             "roofline": {
                 "bound": "mfma",  # fp64 matrix cores for f64, fp32 matrix cores for f32
-                "kernel": "qk_sweep_lean_kernel<4, 1>" if args.precision == "f64" else "qk_sweep_ring_kernel<float>",
+                "kernel": "qk_sweep_ring_kernel<double>" if args.precision == "f64" else "qk_sweep_ring_kernel<float>",
                 "achieved": achieved,
                 "peak": peak,
                 "unit": "TFLOP/s",

@@ -1,0 +1,70 @@
+// qk_host.h -- host-side state shared by the two translation units of libqkgram.so:
+//   qkgram.hip  the C ABI, the planner and the shipped kernels;
+//   qk_lab.hip  the experimental / diagnostic kernels kept for A/B measurements (QK_VARIANT != 20).
+#pragma once
+#include "../../include/qkgram.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <vector>
+
+int qk_fail(int code, const char* fmt, ...) __attribute__((format(printf, 2, 3)));  // sets qk_last_error(), returns code
+
+#define HIP_TRY(expr)                                                                                 \
+  do {                                                                                                \
+    hipError_t e_ = (expr);                                                                           \
+    if (e_ != hipSuccess) return qk_fail(QK_EDEVICE, "%s failed: %s", #expr, hipGetErrorString(e_));  \
+  } while (0)
+
+static constexpr int GMAX = 4;  // pairs per group of the group-sweep lab kernel (sizes its X/T scratch)
+
+struct qk_ctx {
+  int device = 0;
+  int num_cus = 0;
+  hipStream_t own_stream = nullptr;
+  hipStream_t stream = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  bool ev_pending = false;
+  double* scratch = nullptr;
+  size_t scratch_bytes = 0;
+  unsigned long long* counter = nullptr;
+  unsigned long long* prof = nullptr;  // 8 cycle sums of the diagnostic variant
+  int variant = 20;    // sweep kernel variant (QK_VARIANT): 20 = shipped (ring sweep: LDS-DMA ring + 3M product); 17 = lean register-staged sweep;
+                       // 0, 2, 12, 13, 14, 16, 21, 23 = other kernels kept for A/B; 9, 19 = instrumented
+  int wgs_per_cu = 2;  // resident workgroups per CU (QK_WGS_PER_CU)
+  qk_stats last{};
+};
+
+struct qk_mps_set {
+  qk_ctx* ctx = nullptr;
+  int n_states = 0, n_sites = 0, max_pad = 0;
+  int precision = 64;         // bits of a real: 64 (complex128 planes) or 32 (complex64 planes, same element offsets)
+  double* d_data = nullptr;   // the planes; floats when precision == 32
+  int32_t* d_dims = nullptr;  // padded bonds [n_states][n_sites+1]
+  int32_t* d_true = nullptr;  // true bonds   [n_states][n_sites+1]
+  int64_t* d_offs = nullptr;  // re-plane offsets (doubles) [n_states][n_sites]
+  std::vector<int32_t> dims_true;
+  int64_t bytes = 0;
+};
+
+struct qk_plan {
+  int n_sites = 0, nx = 0, ny = 0;
+  bool symmetric = false;
+  int world = 1, rank = 0;
+  int64_t total_pairs = 0, max_per_rank = 0;
+  std::vector<int32_t> pairs;   // this rank, (i, j) interleaved
+  std::vector<int32_t> groups;  // (first pair, count): runs of <= group pairs that share the x state
+  int group = 1;
+  qk_stats stats{};
+  // lazily uploaded copy
+  qk_ctx* up_ctx = nullptr;
+  int32_t* d_pairs = nullptr;
+  int32_t* d_groups = nullptr;
+};
+
+
+struct SweepArgs;
+// qk_lab.hip: raise the LDS limit of the lab kernels; launch lab variant `variant` (returns QK_EINVAL if it is not one)
+int qk_lab_init(qk_ctx* c);
+int qk_lab_launch(qk_ctx* c, int variant, const SweepArgs& a, int grid, int n_sites);

@@ -1,0 +1,358 @@
+// qk_ring.h -- the ring GEMM (LDS-DMA staging ring + 3M complex product) and the sweep kernel built on it:
+// the shipped hot path (qk_sweep_ring_kernel<double>) and its complex64 form (qk_sweep_ring_kernel<float>).
+#pragma once
+#include "qk_device.h"
+
+// ----------------------------------------------------------------------------------------
+// Ring GEMM.  Same 64x64 pass / 8-wave / 2-tiles-per-wave decomposition as zgemm_lean, but
+//   * staging is LDS-DMA (global_load_lds, 16 B per lane) into a ring of three K-tile-8 slots, two
+//     K-tiles in flight across the raw barrier, retired by a counted s_waitcnt vmcnt -- no staging
+//     registers and no ds_write pass;
+//   * the registers this frees hold a third accumulator per tile, so the complex product is the 3M form
+//       P1 += ar*br, P2 += ai*bi, P3 += (ar+ai)*(br+sbi),  sbi = +bi (plain) | -bi (conjugated B)
+//       re = P1 - P2 | P1 + P2,   im = P3 - P1 - P2 | P3 - P1 + P2
+//     three MFMAs per complex k-step instead of four (operand sums: two v_add_f64 on the fragments).
+// Staging roles: waves 0-3 bring the re planes, waves 4-7 the im planes; wave w covers K rows
+// 2(w&3), 2(w&3)+1 of both operands (one 1-KiB wave-linear piece of the A plane and one of the B plane).
+// ----------------------------------------------------------------------------------------
+template <int N>
+__device__ __forceinline__ void qk_wait_const() {
+  static_assert(N >= 0 && N < 64, "vmcnt is a 6-bit field");
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+__device__ __forceinline__ void qk_wait_vm(const int n) {  // wave-uniform n; values above 24 wait for everything
+  switch (n) {
+    case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+    case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+    case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+    case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+    case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+    case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+    case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
+    case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+    case 9: asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); break;
+    case 10: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
+    case 11: asm volatile("s_waitcnt vmcnt(11)" ::: "memory"); break;
+    case 12: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
+    case 13: asm volatile("s_waitcnt vmcnt(13)" ::: "memory"); break;
+    case 14: asm volatile("s_waitcnt vmcnt(14)" ::: "memory"); break;
+    case 15: asm volatile("s_waitcnt vmcnt(15)" ::: "memory"); break;
+    case 16: asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); break;
+    case 17: asm volatile("s_waitcnt vmcnt(17)" ::: "memory"); break;
+    case 18: asm volatile("s_waitcnt vmcnt(18)" ::: "memory"); break;
+    case 19: asm volatile("s_waitcnt vmcnt(19)" ::: "memory"); break;
+    case 20: asm volatile("s_waitcnt vmcnt(20)" ::: "memory"); break;
+    case 21: asm volatile("s_waitcnt vmcnt(21)" ::: "memory"); break;
+    case 22: asm volatile("s_waitcnt vmcnt(22)" ::: "memory"); break;
+    case 23: asm volatile("s_waitcnt vmcnt(23)" ::: "memory"); break;
+    case 24: asm volatile("s_waitcnt vmcnt(24)" ::: "memory"); break;
+    default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+  }
+}
+
+// Scalar traits of the ring GEMM: accumulator vector, MFMA and where an accumulator register lands in the tile.
+template <typename T>
+struct QkScalar;
+template <>
+struct QkScalar<double> {
+  using v4 = v4d;
+  static constexpr int ROW_Q = 1, ROW_R = 4;  // v_mfma_f64_16x16x4_f64: register r of lane (q, j) = C[q + 4r][j]
+  static __device__ __forceinline__ v4 mfma(double a, double b, v4 c) { return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0); }
+};
+template <>
+struct QkScalar<float> {
+  using v4 = v4f;
+  static constexpr int ROW_Q = 4, ROW_R = 1;  // v_mfma_f32_16x16x4_f32: register r of lane (q, j) = C[4q + r][j]
+  static __device__ __forceinline__ v4 mfma(float a, float b, v4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+};
+
+// One complex k-step of one tile.  M3: 3M form (three independent accumulators c1 = P1, c2 = P2, c3 = P3);
+// otherwise the plain four-product form (c1 = re, c2 = im, c3 unused).
+template <bool CONJB, bool M3, typename T>
+__device__ __forceinline__ void mma3_kstep(typename QkScalar<T>::v4& c1, typename QkScalar<T>::v4& c2, typename QkScalar<T>::v4& c3,
+                                           const T ar, const T ai, const T br, const T bi) {
+  using S = QkScalar<T>;
+  if constexpr (M3) {
+    const T sa = ar + ai, sb = CONJB ? br - bi : br + bi;
+    c1 = S::mfma(ar, br, c1);
+    c2 = S::mfma(ai, bi, c2);
+    c3 = S::mfma(sa, sb, c3);
+  } else {
+    const T sbi = CONJB ? -bi : bi;
+    c1 = S::mfma(ar, br, c1);
+    c2 = S::mfma(ar, sbi, c2);
+    c1 = S::mfma(-ai, sbi, c1);
+    c2 = S::mfma(ai, br, c2);
+  }
+}
+
+template <bool CONJB, int CNT, bool FULLK, bool M3, int KTL, int PN = 64, typename T = double>
+__device__ __forceinline__ void mma_ring3(typename QkScalar<T>::v4 (&c1)[2], typename QkScalar<T>::v4 (&c2)[2], typename QkScalar<T>::v4 (&c3)[2],
+                                          const int (&la)[2], const int (&lb)[2], const T* __restrict__ base, const int ksteps) {
+  constexpr int PM = 64, APL = KTL * PM, BPL = KTL * PN, KS = KTL / 4;  // staged planes: A re | A im | B re | B im
+  if constexpr (CNT == 0) return;
+  if constexpr (FULLK) {
+    T far[2], fai[2], fbr[2], fbi[2];
+    auto load = [&](int g, int buf) __attribute__((always_inline)) {
+      const int e = g / KS, ks = g % KS;
+      const T* pa = base + la[e] + 4 * ks * PM;
+      const T* pb = base + lb[e] + 4 * ks * PN;
+      far[buf] = pa[0];
+      fai[buf] = pa[APL];
+      fbr[buf] = pb[0];
+      fbi[buf] = pb[BPL];
+    };
+    load(0, 0);
+#pragma unroll
+    for (int g = 0; g < KS * CNT; ++g) {
+      const int e = g / KS;
+      if (g + 1 < KS * CNT) load(g + 1, (g + 1) & 1);
+      __builtin_amdgcn_sched_barrier(0);
+      mma3_kstep<CONJB, M3, T>(c1[e], c2[e], c3[e], far[g & 1], fai[g & 1], fbr[g & 1], fbi[g & 1]);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  } else {  // the last K-tile of a K range that does not fill it: ksteps in 1..KS-1
+#pragma unroll
+    for (int e = 0; e < CNT; ++e) {
+#pragma unroll
+      for (int ks = 0; ks < KS - 1; ++ks) {
+        if (ks < ksteps) {
+          const T* pa = base + la[e] + 4 * ks * PM;
+          const T* pb = base + lb[e] + 4 * ks * PN;
+          mma3_kstep<CONJB, M3, T>(c1[e], c2[e], c3[e], pa[0], pa[APL], pb[0], pb[BPL]);
+        }
+      }
+    }
+  }
+}
+
+template <bool CONJB, int KTL, int NSLOT, bool M3, int NW = 8, int PN = 64, typename T = double>
+__device__ __forceinline__ void zgemm_ring3(T* __restrict__ Cre, T* __restrict__ Cim, const int ldc,
+                                            const T* __restrict__ Are, const T* __restrict__ Aim, const int lda,
+                                            const T* __restrict__ Bre, const T* __restrict__ Bim, const int ldb,
+                                            const int M, const int N, const int Ktrue, T* __restrict__ lds) {
+  using S = QkScalar<T>;
+  using V4 = typename S::v4;
+  constexpr int EPL = 16 / (int)sizeof(T);            // elements per lane and LDS-DMA (2 doubles / 4 floats)
+  constexpr int CHUNK = 1024 / (int)sizeof(T);        // elements per 1-KiB wave-linear piece
+  constexpr int RPC = CHUNK / 64;                     // K rows of a 64-wide plane per piece (2 / 4)
+  constexpr bool SPLIT = (KTL == 4 * RPC);            // planes of four pieces: waves 0-3 take re, waves 4-7 im
+  static_assert((NW == 8 && PN == 64 && (KTL == 4 * RPC || KTL == 8 * RPC)) || (NW == 4 && PN == 32 && KTL == 8 && sizeof(T) == 8), "supported shapes");
+  constexpr int PM = 64;
+  constexpr int APL = KTL * PM, BPL = KTL * PN, SLOT_D = 2 * APL + 2 * BPL;  // doubles per plane / per ring slot
+  constexpr int DEPTH = NSLOT - 1;                 // K-tiles in flight ahead of the one being multiplied
+  constexpr int LPS = (NW == 4) ? 3 : (SPLIT ? 2 : 4);  // LDS-DMA instructions per wave and K-tile
+  typedef __attribute__((address_space(3))) void* lds_ptr_t;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int j = lane & 15, q = lane >> 4;
+  const int npm = (M + PM - 1) / PM, npn = (N + PN - 1) / PN;
+  const int nk = (Ktrue + KTL - 1) / KTL;
+  const int ks_last = ((Ktrue + 3) >> 2) - (nk - 1) * (KTL / 4);  // k-steps of the last K-tile (1..KTL/4)
+  const int total = npm * npn * nk;
+  const long long sA = (long long)KTL * lda, sB = (long long)KTL * ldb;
+
+  // ---- staging role of this wave / lane: 1-KiB wave-linear pieces of the staged planes.
+  // 8 waves, K-tile 8: waves 0-3 bring the re planes, waves 4-7 the im planes (K rows 2(w&3), +1 of A and of B).
+  // 8 waves, K-tile 16: every wave brings rows 2w, 2w+1 of all four planes.
+  // 4 waves (64x32 pass), K-tile 8: wave w brings rows 2w, 2w+1 of A re and A im, and one of the four 1-KiB pieces
+  // of the B planes (plane w>>1, K rows 4(w&1) .. +3; a B row is 32 doubles).
+  const int w3 = (NW == 8 && SPLIT) ? (wave & 3) : wave;
+  const int pl = (NW == 8 && SPLIT) ? (wave >> 2) : 0;
+  const long long a_im = Aim - Are, b_im = Bim - Bre;  // plane strides of the operands
+  const T* const Asrc = pl ? Aim : Are;
+  const T* const Bsrc = (NW == 4) ? ((wave >> 1) ? Bim : Bre) : (pl ? Bim : Bre);
+  constexpr int LPR = 64 / RPC;                        // lanes per 64-wide K row of a piece
+  const int srow = RPC * w3 + lane / LPR, scol = (lane % LPR) * EPL;
+  const int srowB = (NW == 4) ? 4 * (wave & 1) + (lane >> 4) : srow;
+  const int scolB = (NW == 4) ? (lane & 15) * 2 : scol;
+  const unsigned rA = (unsigned)(srow * lda), rB = (unsigned)(srowB * ldb);
+  T* const dA = lds + pl * APL + w3 * CHUNK;           // slot 0 destinations (wave-uniform)
+  T* const dB = (NW == 4) ? lds + 2 * APL + (wave >> 1) * BPL + (wave & 1) * CHUNK : lds + 2 * APL + pl * BPL + w3 * CHUNK;
+
+  // ---- fetch-side pass state (runs DEPTH K-tiles ahead of the compute side, across pass boundaries)
+  int f_pm = 0, f_pn = 0, f_left = nk, f_slot = 0;
+  const T *fa = Asrc, *fb = Bsrc;
+  unsigned offA = rA + (unsigned)min(scol, min(PM, M) - EPL), offB = rB + (unsigned)min(scolB, min(PN, N) - EPL);
+  auto fetch = [&]() __attribute__((always_inline)) {
+    __builtin_amdgcn_global_load_lds(fa + offA, (lds_ptr_t)(dA + f_slot), 16, 0, 0);
+    if constexpr (!SPLIT || NW == 4) __builtin_amdgcn_global_load_lds(fa + a_im + offA, (lds_ptr_t)(dA + APL + f_slot), 16, 0, 0);
+    __builtin_amdgcn_global_load_lds(fb + offB, (lds_ptr_t)(dB + f_slot), 16, 0, 0);
+    if constexpr (!SPLIT && NW == 8) __builtin_amdgcn_global_load_lds(fb + b_im + offB, (lds_ptr_t)(dB + BPL + f_slot), 16, 0, 0);
+    fa += sA, fb += sB;
+    f_slot = (f_slot == (NSLOT - 1) * SLOT_D) ? 0 : f_slot + SLOT_D;
+    if (--f_left == 0) {
+      if (++f_pm == npm) f_pm = 0, ++f_pn;
+      const int m0 = f_pm * PM, n0 = f_pn * PN;
+      fa = Asrc + m0, fb = Bsrc + n0;
+      offA = rA + (unsigned)min(scol, min(PM, M - m0) - EPL);
+      offB = rB + (unsigned)min(scolB, min(PN, N - n0) - EPL);
+      f_left = nk;
+    }
+  };
+
+  // ---- step counters shared by all passes
+  int s = 0, c_slot = 0, pend = 0;
+  const int crow = S::ROW_R * ldc;
+
+  // One pass = nk steps on one 64x64 output tile, specialised on the number of tiles this wave owns so that
+  // the MFMA block is branch-free and the accumulators live only inside the pass.
+  auto run_pass = [&](auto cnt_tag, const int m0, const int n0, const int mt, const int vt) __attribute__((always_inline)) {
+    constexpr int CNT = decltype(cnt_tag)::value;
+    int la[2], lb[2], co[2];
+    V4 c1[2], c2[2], c3[2];
+    const int inv = (mt == 1) ? 32 : (mt == 2) ? 16 : (mt == 3) ? 11 : 8;  // t / mt == (t * inv) >> 5 for t < 16
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      const int t = min(wave + NW * e, vt - 1);
+      const int tn = (t * inv) >> 5, tm = t - tn * mt;
+      la[e] = q * PM + tm * TILE + j;
+      lb[e] = 2 * APL + q * PN + tn * TILE + j;
+      co[e] = (m0 + tm * TILE + S::ROW_Q * q) * ldc + n0 + tn * TILE + j;
+      c1[e] = (V4){0, 0, 0, 0};
+      c2[e] = (V4){0, 0, 0, 0};
+      c3[e] = (V4){0, 0, 0, 0};
+    }
+    for (int kt = 0; kt < nk; ++kt, ++s) {  // (ring)
+      if (s + DEPTH < total) fetch();                    // K-tile s+DEPTH -> the slot read in step s-1
+      const T* base = lds + c_slot;
+      if (kt + 1 < nk || ks_last == KTL / 4) mma_ring3<CONJB, CNT, true, M3, KTL, PN, T>(c1, c2, c3, la, lb, base, KTL / 4);
+      else mma_ring3<CONJB, CNT, false, M3, KTL, PN, T>(c1, c2, c3, la, lb, base, ks_last);
+      if (s + 1 < total) {
+        // K-tile s+1 must have landed; everything issued after it may stay in flight: the younger K-tiles and,
+        // when it was issued before the previous step's epilogue (DEPTH >= 2), that epilogue's stores
+        const int young = LPS * min(DEPTH - 1, total - 2 - s);
+        if (DEPTH == 1 || pend == 0) {  // the common case first: the generic switch costs a branch tree per step
+          if (young == LPS * (DEPTH - 1)) qk_wait_const<LPS * (DEPTH - 1)>();
+          else qk_wait_vm(young);
+        } else {
+          qk_wait_vm(young + pend);
+        }
+        qk_lds_barrier();
+      }
+      pend = 0;
+      c_slot = (c_slot == (NSLOT - 1) * SLOT_D) ? 0 : c_slot + SLOT_D;
+    }
+    if constexpr (CNT > 0) {
+#pragma unroll
+      for (int e = 0; e < CNT; ++e) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          if constexpr (M3) {
+            const T p1 = c1[e][r], p2 = c2[e][r], p3 = c3[e][r];
+            Cre[co[e] + r * crow] = CONJB ? p1 + p2 : p1 - p2;
+            Cim[co[e] + r * crow] = CONJB ? (p3 - p1) + p2 : (p3 - p1) - p2;
+          } else {
+            Cre[co[e] + r * crow] = c1[e][r];
+            Cim[co[e] + r * crow] = c2[e][r];
+          }
+        }
+      }
+      pend = 8 * CNT;
+    }
+  };
+
+#pragma unroll
+  for (int i = 0; i < DEPTH; ++i)
+    if (i < total) fetch();
+  qk_wait_vm(LPS * (min(DEPTH, total) - 1));
+  qk_lds_barrier();
+  for (int pn = 0; pn < npn; ++pn) {
+    for (int pm = 0; pm < npm; ++pm) {
+      const int m0 = pm * PM, n0 = pn * PN;
+      const int mt = min(PM / TILE, (M - m0) / TILE), nt = min(PN / TILE, (N - n0) / TILE);
+      const int vt = mt * nt;
+      const int cnt = (vt > wave) ? (vt - wave + NW - 1) / NW : 0;
+      if (cnt == 2) run_pass(std::integral_constant<int, 2>{}, m0, n0, mt, vt);
+      else if (cnt == 1) run_pass(std::integral_constant<int, 1>{}, m0, n0, mt, vt);
+      else run_pass(std::integral_constant<int, 0>{}, m0, n0, mt, vt);
+    }
+  }
+  __syncthreads();
+}
+
+// ----------------------------------------------------------------------------------------
+// The ring sweep as its own kernel, templated on the scalar type:
+//   T = double: the same code path as qk_sweep_lean_kernel<4, 1> (K-tile 8);
+//   T = float : complex64 sweep on v_mfma_f32_16x16x4_f32 (K-tile 16: the same 16-KiB slots, pieces and roles).
+// The MPS set is read as T planes with the SAME element offsets as the fp64 image (qk_mps_set_to_f32 converts
+// element by element), the X/T scratch holds T, the outputs are doubles.
+// ----------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(512, 4) void qk_sweep_ring_kernel(const SweepArgs g) {
+  constexpr int NW = 8;
+  constexpr int KTL = 32 / (int)sizeof(T) * 2;  // 8 rows of doubles, 16 rows of floats: 16-KiB slots either way
+  constexpr int SLOT_BYTES = 16 * 1024, NSLOT = 3;
+  extern __shared__ __attribute__((aligned(16))) double lds_raw[];
+  T* lds = reinterpret_cast<T*>(lds_raw);
+  long long* slot = reinterpret_cast<long long*>(reinterpret_cast<char*>(lds_raw) + NSLOT * SLOT_BYTES);
+  const T* xdata = reinterpret_cast<const T*>(g.xdata);
+  const T* ydata = reinterpret_cast<const T*>(g.ydata);
+  T* Xre = reinterpret_cast<T*>(g.scratch) + (long long)blockIdx.x * 2 * (g.x_plane + g.t_plane);
+  T* Xim = Xre + g.x_plane;
+  T* Tre = Xim + g.x_plane;
+  T* Tim = Tre + g.t_plane;
+  const int tid = threadIdx.x;
+  for (;;) {
+    if (tid == 0) *slot = (long long)atomicAdd(g.counter, 1ull);
+    __syncthreads();
+    const long long p = *slot;
+    __syncthreads();
+    if (p >= g.npairs) break;
+    const int xi = g.pairs[2 * p], yj = g.pairs[2 * p + 1];
+    // per-site metadata of the pair, staged once: [xd | yd | xt | yt] (n+1 ints each) then [xo | yo] (n int64)
+    const int n1 = g.n_sites + 1;
+    int* m_xd = reinterpret_cast<int*>(slot + 2);
+    int* m_yd = m_xd + n1;
+    int* m_xt = m_yd + n1;
+    int* m_yt = m_xt + n1;
+    long long* m_xo = reinterpret_cast<long long*>(m_xd + 4 * n1 + (4 * n1 & 1));
+    long long* m_yo = m_xo + g.n_sites;
+    for (int e = tid; e < n1; e += 64 * NW) {
+      m_xd[e] = g.xdims[(long long)xi * n1 + e];
+      m_yd[e] = g.ydims[(long long)yj * n1 + e];
+      m_xt[e] = g.xtrue[(long long)xi * n1 + e];
+      m_yt[e] = g.ytrue[(long long)yj * n1 + e];
+      if (e < g.n_sites) {
+        m_xo[e] = g.xoffs[(long long)xi * g.n_sites + e];
+        m_yo[e] = g.yoffs[(long long)yj * g.n_sites + e];
+      }
+    }
+    __syncthreads();
+    auto ldi = [&](const int* q_) __attribute__((always_inline)) { return __builtin_amdgcn_readfirstlane(*q_); };
+    auto ldl = [&](const long long* q_) __attribute__((always_inline)) {
+      const long long v = *q_;
+      const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v);
+      const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)((unsigned long long)v >> 32));
+      return (long long)(((unsigned long long)hi << 32) | lo);
+    };
+    {
+      const int a = ldi(m_xd), b = ldi(m_yd);
+      for (int e = tid; e < a * b; e += 64 * NW) {
+        Xre[e] = (e == 0) ? (T)1 : (T)0;
+        Xim[e] = (T)0;
+      }
+      __syncthreads();
+    }
+    for (int k = 0; k < g.n_sites; ++k) {
+      const int a = ldi(m_xd + k), a2 = ldi(m_xd + k + 1), b = ldi(m_yd + k), b2 = ldi(m_yd + k + 1);
+      const T* Are = xdata + ldl(m_xo + k);
+      const T* Aim = Are + (long long)a * 2 * a2;
+      const T* Bre = ydata + ldl(m_yo + k);
+      const T* Bim = Bre + (long long)b * 2 * b2;
+      zgemm_ring3<false, KTL, NSLOT, true, NW, 64>(Tre, Tim, 2 * b2, Xre, Xim, a, Bre, Bim, 2 * b2, a, 2 * b2, ldi(m_yt + k), lds);
+      zgemm_ring3<true, KTL, NSLOT, true, NW, 64>(Xre, Xim, a2, Tre, Tim, b2, Are, Aim, a2, b2, a2, 2 * ldi(m_xt + k), lds);
+    }
+    if (tid == 0) {
+      const double re = (double)Xre[0], im = (double)Xim[0];
+      g.values[p] = re * re + im * im;
+      if (g.z) {
+        g.z[2 * p] = re;
+        g.z[2 * p + 1] = im;
+      }
+    }
+    __syncthreads();
+  }
+}
