@@ -4,16 +4,32 @@
 #include "qk_device.h"
 
 // ----------------------------------------------------------------------------------------
-// Ring GEMM.  Same 64x64 pass / 8-wave / 2-tiles-per-wave decomposition as zgemm_lean, but
-//   * staging is LDS-DMA (global_load_lds, 16 B per lane) into a ring of three K-tile-8 slots, two
-//     K-tiles in flight across the raw barrier, retired by a counted s_waitcnt vmcnt -- no staging
-//     registers and no ds_write pass;
+// The sweep.  For a pair (x, y) of n-site MPS the overlap is a chain of 2n complex GEMMs on the matrix cores,
+//     X_0 = 1
+//     T [a x 2b'] = X^T . B_k          (M = a,  N = 2b', K = b : B_k = site k of y as a [b][(p, b')] matrix)
+//     X'[b' x a'] = T^T . conj(A_k)    (M = b', N = a',  K = 2a: T re-read as a [(a, p)][b'] matrix, A_k = site k of x)
+//     <x|y> = X_n[0][0]
+// (reference: MPS.vdot, gpu_backend/kernel_state_ansatz.py:380; KernelPkg.jl:106).  Every operand is "k-major"
+// (row k holds the M resp. N entries contiguously) in split re/im planes, so nothing is ever transposed.
+//
+// Ring GEMM  C[M x N] = sum_k Aop[k][m] * Bop[k][n]  (CONJB conjugates Bop), all 8 waves of the workgroup together:
+//   * a pass produces one 64x64 complex output block; a wave owns up to two of its sixteen 16x16 tiles, dealt
+//     round-robin over the VALID tiles so ragged edge blocks stay balanced;
+//   * staging is LDS-DMA (global_load_lds, 16 B per lane) into a ring of three K-tile slots (16 KiB each: planes
+//     A re | A im | B re | B im of [KTL][64]), two K-tiles in flight across a raw barrier, retired by a counted
+//     s_waitcnt vmcnt -- no staging registers and no ds_write pass.  The (pass, K-tile) space of a GEMM is ONE flat
+//     sequence of steps: the fetch side runs ahead of the compute side across pass boundaries;
 //   * the registers this frees hold a third accumulator per tile, so the complex product is the 3M form
 //       P1 += ar*br, P2 += ai*bi, P3 += (ar+ai)*(br+sbi),  sbi = +bi (plain) | -bi (conjugated B)
 //       re = P1 - P2 | P1 + P2,   im = P3 - P1 - P2 | P3 - P1 + P2
-//     three MFMAs per complex k-step instead of four (operand sums: two v_add_f64 on the fragments).
-// Staging roles: waves 0-3 bring the re planes, waves 4-7 the im planes; wave w covers K rows
-// 2(w&3), 2(w&3)+1 of both operands (one 1-KiB wave-linear piece of the A plane and one of the B plane).
+//     three MFMAs per complex k-step instead of four (operand sums: two adds on the fragments);
+//   * K is walked in units of 4 (the MFMA k extent) up to the TRUE bond, not the padded one.
+// MFMA fragment maps (lane = 16 q + j), checked on the device by qk_selftest_mfma:
+//   A operand: lane holds Aop_tile[i = j][k = q] -> staged element [4 ks + q][16 tm + j];  B likewise with tn;
+//   C/D: register r of the lane is C_tile[q + 4 r][j] (f64 16x16x4) or C_tile[4 q + r][j] (f32 16x16x4).
+// Staging roles (SPLIT case: K-tile 8 of doubles / 16 of floats): waves 0-3 bring the re planes, waves 4-7 the im
+// planes; wave w covers the K rows of piece w & 3 of both operands (one 1-KiB wave-linear piece of the A plane and
+// one of the B plane); loads are unconditional, columns clamped into the valid range.
 // ----------------------------------------------------------------------------------------
 template <int N>
 __device__ __forceinline__ void qk_wait_const() {
@@ -274,11 +290,13 @@ __device__ __forceinline__ void zgemm_ring3(T* __restrict__ Cre, T* __restrict__
 }
 
 // ----------------------------------------------------------------------------------------
-// The ring sweep as its own kernel, templated on the scalar type:
-//   T = double: the same code path as qk_sweep_lean_kernel<4, 1> (K-tile 8);
-//   T = float : complex64 sweep on v_mfma_f32_16x16x4_f32 (K-tile 16: the same 16-KiB slots, pieces and roles).
-// The MPS set is read as T planes with the SAME element offsets as the fp64 image (qk_mps_set_to_f32 converts
-// element by element), the X/T scratch holds T, the outputs are doubles.
+// The sweep kernel: ONE persistent launch per Gram share.  Grid = 2 workgroups per CU, 8 waves each.  A workgroup
+// pulls pair indices from a device counter and carries the whole sweep of that pair; X and T live in a private
+// global scratch (L2 / Infinity Cache resident), the result |<x|y>|^2 (and z) is written as doubles.
+//   T = double: the shipped hot path (K-tile 8);
+//   T = float : complex64 sweep on v_mfma_f32_16x16x4_f32 (K-tile 16: the same 16-KiB slots, pieces
+//               and roles).  The set is read as float planes with the SAME element offsets as the fp64 image
+//               (qk_mps_set_to_f32 converts element by element); the X/T scratch holds floats.
 // ----------------------------------------------------------------------------------------
 template <typename T>
 __global__ __launch_bounds__(512, 4) void qk_sweep_ring_kernel(const SweepArgs g) {

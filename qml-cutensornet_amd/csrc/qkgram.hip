@@ -9,6 +9,9 @@
 // on chip/L2 as a chain of complex GEMMs on the f64 matrix cores
 // (v_mfma_f64_16x16x4_f64), and finally writes |<x|y>|^2.
 //
+//
+// Files: this one = C ABI (include/qkgram.h), packing, planner, small kernels, launches;  qk_ring.h = the sweep
+// kernels (the hot path);  qk_lab.hip = experimental / diagnostic kernels selectable with QK_VARIANT.
 // Written for gfx950 only: 64-lane wavefronts, 160 KiB LDS per CU, no portability layer.
 #include "qk_host.h"
 #include "qk_ring.h"
