@@ -40,6 +40,10 @@ extern "C" {
 
 /* flags of qk_plan_create() */
 #define QK_PLAN_SYMMETRIC 1u /* Y is X: compute i <= j only, mirror on scatter (G:390-395) */
+#define QK_PLAN_QUADS 2u     /* pairs in 2x2 blocks {i1,i2} x {j1,j2} of consecutive states: one workgroup sweeps a block in
+                                lockstep (experimental: measured no faster than pairs on cfg4).  The pair list then holds 4 entries per
+                                block (a symmetric plan's diagonal blocks include one mirrored pair i > j, an odd set's last
+                                block repeats its state): scatter handles both. */
 
 typedef struct qk_ctx qk_ctx;         /* one per device; replaces CuTensorNetHandle(device_id), G:213,255,366 */
 typedef struct qk_mps_set qk_mps_set; /* a device-resident list of MPS; replaces the per-rank lists of

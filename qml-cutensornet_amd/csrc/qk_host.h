@@ -51,6 +51,7 @@ struct qk_mps_set {
 struct qk_plan {
   int n_sites = 0, nx = 0, ny = 0;
   bool symmetric = false;
+  bool quad = false;  // pairs come in 2x2 blocks (QK_PLAN_QUADS): [4q..4q+3] = (i1,j1), (i2,j1), (i1,j2), (i2,j2)
   int world = 1, rank = 0;
   int64_t total_pairs = 0, max_per_rank = 0;
   std::vector<int32_t> pairs;   // this rank, (i, j) interleaved
@@ -68,3 +69,4 @@ struct SweepArgs;
 // qk_lab.hip: raise the LDS limit of the lab kernels; launch lab variant `variant` (returns QK_EINVAL if it is not one)
 int qk_lab_init(qk_ctx* c);
 int qk_lab_launch(qk_ctx* c, int variant, const SweepArgs& a, int grid, int n_sites);
+int qk_lab_launch_quad(qk_ctx* c, const SweepArgs& a, int grid, int n_sites, bool f32);  // QK_PLAN_QUADS plans

@@ -1618,10 +1618,133 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 ? 4 : 2)) void qk_mma_bench_kerne
 
 
 // ----------------------------------------------------------------------------------------
+// Quad sweep: one workgroup carries the 2x2 block of pairs {x1, x2} x {y1, y2} through the chain in lockstep.
+// Per y_j the two environments sit side by side in one k-major matrix  XB_j = [X_1j | X_2j]  ([b_j][a_1 + a_2]), so
+//   phase 1:  TB_j [(a_1 + a_2) x 2b'_j] = XB_j^T . B_kj           ONE GEMM per y_j: the site tensor of y_j is read
+//                                                                   once for two pairs and M is doubled;
+//   phase 2:  X'_ij [b'_j x a'_i] = T_ij^T . conj(A_ki)            per (i, j), T_ij = the a_i rows of TB_j, written into
+//                                                                   XB'_j at column offset (i = 2 ? a'_1 : 0);  the two
+//                                                                   reads of A_ki follow each other (second one from L2).
+// Six GEMM calls per site for four pairs instead of eight, the same ring GEMM.  MEASURED (cfg4): 539 vs 526 ms for the
+// pair kernel, fabric reads 2.16 vs 2.22 TB -- the stacked GEMM has two M passes and re-reads the B panel for each, so
+// the shared site tensor is not read less; kept as an option (QK_PLAN_QUADS plans) because it is correct and tested.  pairs[4q .. 4q+3] = (x1,y1), (x2,y1), (x1,y2), (x2,y2); a duo may name the same state twice (odd set
+// sizes): the duplicate is computed redundantly.  Scratch per workgroup: 2 x (XB_j planes + TB_j planes).
+// ----------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(512, 4) void qk_sweep_quad_kernel(const SweepArgs g) {
+  constexpr int NW = 8;
+  constexpr int KTL = 32 / (int)sizeof(T) * 2;
+  constexpr int SLOT_BYTES = 16 * 1024, NSLOT = 3;
+  extern __shared__ __attribute__((aligned(16))) double lds_raw[];
+  T* lds = reinterpret_cast<T*>(lds_raw);
+  long long* slot = reinterpret_cast<long long*>(reinterpret_cast<char*>(lds_raw) + NSLOT * SLOT_BYTES);
+  const T* xdata = reinterpret_cast<const T*>(g.xdata);
+  const T* ydata = reinterpret_cast<const T*>(g.ydata);
+  const long long xp = 2 * g.x_plane, tp = 2 * g.t_plane;  // planes of the stacked buffers
+  T* const base = reinterpret_cast<T*>(g.scratch) + (long long)blockIdx.x * 4 * (xp + tp);
+  const long long jstride = 2 * (xp + tp);  // XB_j = base + j * jstride
+  const int tid = threadIdx.x;
+  const long long nquads = g.npairs / 4;
+  for (;;) {
+    if (tid == 0) *slot = (long long)atomicAdd(g.counter, 1ull);
+    __syncthreads();
+    const long long qd = *slot;
+    __syncthreads();
+    if (qd >= nquads) break;
+    const int x1 = g.pairs[8 * qd], y1 = g.pairs[8 * qd + 1], x2 = g.pairs[8 * qd + 2], y2 = g.pairs[8 * qd + 5];
+    // per-site metadata of the four states: [xd1 | xd2 | yd1 | yd2 | xt1 | xt2 | yt1 | yt2] (n+1 ints each), then
+    // [xo1 | xo2 | yo1 | yo2] (n int64 each)
+    const int n1 = g.n_sites + 1, ns = g.n_sites;
+    int* md = reinterpret_cast<int*>(slot + 2);
+    long long* mo = reinterpret_cast<long long*>(md + 8 * n1 + (8 * n1 & 1));
+    for (int e = tid; e < n1; e += 64 * NW) {
+      md[e] = g.xdims[(long long)x1 * n1 + e];
+      md[n1 + e] = g.xdims[(long long)x2 * n1 + e];
+      md[2 * n1 + e] = g.ydims[(long long)y1 * n1 + e];
+      md[3 * n1 + e] = g.ydims[(long long)y2 * n1 + e];
+      md[4 * n1 + e] = g.xtrue[(long long)x1 * n1 + e];
+      md[5 * n1 + e] = g.xtrue[(long long)x2 * n1 + e];
+      md[6 * n1 + e] = g.ytrue[(long long)y1 * n1 + e];
+      md[7 * n1 + e] = g.ytrue[(long long)y2 * n1 + e];
+      if (e < ns) {
+        mo[e] = g.xoffs[(long long)x1 * ns + e];
+        mo[ns + e] = g.xoffs[(long long)x2 * ns + e];
+        mo[2 * ns + e] = g.yoffs[(long long)y1 * ns + e];
+        mo[3 * ns + e] = g.yoffs[(long long)y2 * ns + e];
+      }
+    }
+    __syncthreads();
+    auto ldi = [&](const int* q_) __attribute__((always_inline)) { return __builtin_amdgcn_readfirstlane(*q_); };
+    auto ldl = [&](const long long* q_) __attribute__((always_inline)) {
+      const long long v = *q_;
+      const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v);
+      const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)((unsigned long long)v >> 32));
+      return (long long)(((unsigned long long)hi << 32) | lo);
+    };
+    {  // XB_j at site 0: [b_j = 16 rows][a_1 + a_2 = 32 columns], X_1j[0][0] = X_2j[0][0] = 1
+      const int a1 = ldi(md), A2 = a1 + ldi(md + n1);
+      for (int j = 0; j < 2; ++j) {
+        const int b = ldi(md + (2 + j) * n1);
+        T* Xre = base + j * jstride;
+        T* Xim = Xre + xp;
+        for (int e = tid; e < b * A2; e += 64 * NW) {
+          Xre[e] = (e == 0 || e == a1) ? (T)1 : (T)0;
+          Xim[e] = (T)0;
+        }
+      }
+      __syncthreads();
+    }
+    for (int k = 0; k < ns; ++k) {
+      const int a1 = ldi(md + k), a2 = ldi(md + n1 + k), a1n = ldi(md + k + 1), a2n = ldi(md + n1 + k + 1);
+      const int A2 = a1 + a2, A2n = a1n + a2n;
+      for (int j = 0; j < 2; ++j) {  // phase 1: TB_j = XB_j^T B_j, contraction over the TRUE bond of y_j
+        const int b = ldi(md + (2 + j) * n1 + k), bn = ldi(md + (2 + j) * n1 + k + 1);
+        const T* Bre = ydata + ldl(mo + (2 + j) * ns + k);
+        const T* Bim = Bre + (long long)b * 2 * bn;
+        T* Xre = base + j * jstride;
+        T* Xim = Xre + xp;
+        T* Tre = Xim + xp;
+        T* Tim = Tre + tp;
+        zgemm_ring3<false, KTL, NSLOT, true, NW, 64, T, 1>(Tre, Tim, 2 * bn, Xre, Xim, A2, Bre, Bim, 2 * bn, A2, 2 * bn, ldi(md + (6 + j) * n1 + k), lds);
+      }
+      for (int jj = 0; jj < 4; ++jj) {  // phase 2: X'_ij = T_ij^T conj(A_i), contraction over the 2 a_i TRUE rows (a, p)
+        const int i = jj >> 1, j = jj & 1;  // order (i, j) = (1,1) (1,2) (2,1) (2,2): the two reads of A_i follow each other
+        const int bn = ldi(md + (2 + j) * n1 + k + 1);
+        T* Xre = base + j * jstride;
+        T* Xim = Xre + xp;
+        T* Tre = Xim + xp;
+        T* Tim = Tre + tp;
+        const int a = i ? a2 : a1, an = i ? a2n : a1n;
+        const T* Are = xdata + ldl(mo + i * ns + k);
+        const T* Aim = Are + (long long)a * 2 * an;
+        const long long trow = i ? (long long)a1 * 2 * bn : 0;  // T_2j starts after the a_1 rows of TB_j
+        const int ccol = i ? a1n : 0;
+        zgemm_ring3<true, KTL, NSLOT, true, NW, 64, T, 1>(Xre + ccol, Xim + ccol, A2n, Tre + trow, Tim + trow, bn, Are, Aim, an, bn, an, 2 * ldi(md + (4 + i) * n1 + k), lds);
+      }
+    }
+    if (tid < 4) {  // XB_j is [16][32] now: z_1j at [0][0], z_2j at [0][a_1 = 16]
+      const int j = tid >> 1, i = tid & 1;
+      const int a1n = md[ns];
+      const T* Xre = base + j * jstride;
+      const double re = (double)Xre[i ? a1n : 0], im = (double)Xre[xp + (i ? a1n : 0)];
+      const long long p = 4 * qd + 2 * j + i;
+      g.values[p] = re * re + im * im;
+      if (g.z) {
+        g.z[2 * p] = re;
+        g.z[2 * p + 1] = im;
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// ----------------------------------------------------------------------------------------
 // host side of the lab
 // ----------------------------------------------------------------------------------------
 int qk_lab_init(qk_ctx* c) {
   (void)c;
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(qk_sweep_quad_kernel<double>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(qk_sweep_quad_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(qk_sweep_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(qk_sweep_flat_kernel<64, 16, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)GemmCfg<64, 16>::LDS_B));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(qk_sweep_flat_kernel<64, 16, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)GemmCfg<64, 16>::LDS_B));
@@ -1650,6 +1773,14 @@ int qk_lab_init(qk_ctx* c) {
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(qk_mma_bench_kernel<8, 23>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)GemmCfg<64, 16, 4, 64>::LDS_B));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(qk_mma_bench_kernel<8, 31>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)GemmCfg<64, 16, 4, 64>::LDS_B));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(qk_mma_bench_kernel<8, 63>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)GemmCfg<64, 16, 4, 64>::LDS_B));
+  return QK_OK;
+}
+
+int qk_lab_launch_quad(qk_ctx* c, const SweepArgs& a, int grid, int n_sites, bool f32) {
+  const size_t lds_quad = 3 * 16 * 1024 + 16 + (size_t)(8 * (n_sites + 1) + 2) * sizeof(int) + (size_t)4 * n_sites * sizeof(long long);
+  if (lds_quad > 80 * 1024) return fail(QK_EINVAL, "qk_gram_values: %d sites need %zu bytes of LDS per workgroup (limit 80 KiB for 2 workgroups per CU)", n_sites, lds_quad);
+  if (f32) qk_sweep_quad_kernel<float><<<dim3(grid), dim3(512), lds_quad, c->stream>>>(a);
+  else qk_sweep_quad_kernel<double><<<dim3(grid), dim3(512), lds_quad, c->stream>>>(a);
   return QK_OK;
 }
 

@@ -143,7 +143,9 @@ __device__ __forceinline__ void mma_ring3(typename QkScalar<T>::v4 (&c1)[2], typ
   }
 }
 
-template <bool CONJB, int KTL, int NSLOT, bool M3, int NW = 8, int PN = 64, typename T = double>
+// (USER only tells instantiations from different kernels apart: hipcc's host pass rejects a second kernel that
+// calls the very same specialisation.)
+template <bool CONJB, int KTL, int NSLOT, bool M3, int NW = 8, int PN = 64, typename T = double, int USER = 0>
 __device__ __forceinline__ void zgemm_ring3(T* __restrict__ Cre, T* __restrict__ Cim, const int ldc,
                                             const T* __restrict__ Are, const T* __restrict__ Aim, const int lda,
                                             const T* __restrict__ Bre, const T* __restrict__ Bim, const int ldb,

@@ -126,6 +126,64 @@ extern "C" int qk_plan_create(int32_t n_sites, int32_t nx, const int32_t* x_dims
     int32_t i, j;
     float cost;
   };
+  if (flags & QK_PLAN_QUADS) {
+    // 2x2 blocks of pairs {i1, i2} x {j1, j2} (duos of consecutive states; the last duo of an odd set names its state
+    // twice).  A symmetric Gram takes the duo pairs u <= v; its diagonal blocks then hold one mirrored pair (i > j) that
+    // is computed redundantly.  Blocks are ordered by decreasing cost and dealt in serpentine order like pairs.
+    p->quad = true;
+    const int stride = n_sites + 1;
+    const int nxd = (nx + 1) / 2, nyd = (ny + 1) / 2;
+    struct Quad {
+      int32_t i1, i2, j1, j2;
+      double cost;
+    };
+    std::vector<Quad> quads;
+    auto work = [&](int i, int j, double* f, double* fp, double* by) { pair_work(n_sites, x_dims + (int64_t)i * stride, y_dims + (int64_t)j * stride, f, fp, by); };
+    for (int v = 0; v < nyd; ++v)
+      for (int u = 0; u < nxd; ++u) {
+        if (sym && u > v) continue;
+        Quad q{2 * u, std::min(2 * u + 1, nx - 1), 2 * v, std::min(2 * v + 1, ny - 1), 0.0};
+        const int32_t is[2] = {q.i1, q.i2}, js[2] = {q.j1, q.j2};
+        for (int b = 0; b < 2; ++b)
+          for (int a = 0; a < 2; ++a) {
+            double f, fp, by;
+            work(is[a], js[b], &f, &fp, &by);
+            q.cost += fp;
+          }
+        quads.push_back(q);
+      }
+    std::stable_sort(quads.begin(), quads.end(), [](const Quad& a, const Quad& b) { return a.cost > b.cost; });
+    std::vector<int64_t> per_rank(world_size, 0);
+    double flops = 0, padded = 0, bytes = 0;
+    int64_t t = 0;
+    for (const Quad& q : quads) {
+      const int64_t u = t % (2 * (int64_t)world_size);
+      const int r = (int)(u < world_size ? u : 2 * (int64_t)world_size - 1 - u);
+      per_rank[r] += 4;
+      if (r == rank) {
+        const int32_t is[2] = {q.i1, q.i2}, js[2] = {q.j1, q.j2};
+        for (int b = 0; b < 2; ++b)
+          for (int a = 0; a < 2; ++a) {
+            p->pairs.push_back(is[a]);
+            p->pairs.push_back(js[b]);
+            const bool redundant = (a == 1 && q.i2 == q.i1) || (b == 1 && q.j2 == q.j1) || (sym && is[a] > js[b]);
+            if (!redundant) {
+              double f, fp, by;
+              work(is[a], js[b], &f, &fp, &by);
+              flops += f, padded += fp, bytes += by;
+            }
+          }
+      }
+      ++t;
+    }
+    p->groups = {0, 0};
+    p->total_pairs = 4 * t;
+    p->max_per_rank = *std::max_element(per_rank.begin(), per_rank.end());
+    p->stats.pairs = (int64_t)p->pairs.size() / 2;
+    p->stats.flops = flops, p->stats.padded_flops = padded, p->stats.bytes = bytes;
+    *out = p;
+    return QK_OK;
+  }
   std::vector<Item> tile;
   const int stride = n_sites + 1;
   int64_t t = 0;  // running index in the global order
@@ -490,13 +548,14 @@ extern "C" int qk_gram_values(qk_ctx* c, const qk_mps_set* xs, const qk_mps_set*
   if (xs->precision != ys->precision) return fail(QK_EINVAL, "qk_gram_values: the two sets differ in precision (fp%d, fp%d)", xs->precision, ys->precision);
   const bool f32 = (xs->precision == 32);
   if (f32) c->last.bytes *= 0.5;  // complex64 planes
-  const bool grouped = (c->variant == 14) && !f32;
-  const bool duo = (c->variant == 16) && !f32;
-  const long long members = grouped ? GMAX : 1;  // pairs stacked in one X/T buffer
-  const long long chains = duo ? 2 : 1;          // independent X/T buffer sets per workgroup
+  const bool quad = plan->quad;
+  const bool grouped = (c->variant == 14) && !f32 && !quad;
+  const bool duo = (c->variant == 16) && !f32 && !quad;
+  const long long members = grouped ? GMAX : 1;        // pairs stacked in one X/T buffer (the quad kernel doubles the planes itself)
+  const long long chains = quad ? 4 : (duo ? 2 : 1);  // X/T buffer sets per workgroup (quad: 2 stacked sets = 4 single ones)
   const long long x_plane = members * xs->max_pad * ys->max_pad;
   const long long t_plane = 2 * x_plane;
-  const long long units = grouped ? (long long)plan->groups.size() / 2 : (duo ? (np + 1) / 2 : np);
+  const long long units = quad ? np / 4 : grouped ? (long long)plan->groups.size() / 2 : (duo ? (np + 1) / 2 : np);
   const int grid = (int)std::min<long long>(units, (long long)c->wgs_per_cu * c->num_cus);
   const size_t need = (size_t)grid * (size_t)chains * 2 * (size_t)(x_plane + t_plane) * sizeof(double);
   if (need > c->scratch_bytes) {
@@ -525,7 +584,10 @@ extern "C" int qk_gram_values(qk_ctx* c, const qk_mps_set* xs, const qk_mps_set*
   // per-pair site metadata in LDS behind the three ring slots: 4 (n+1) ints + 2 n int64 (+ alignment)
   const size_t lds_ring = 3 * 16 * 1024 + 16 + (size_t)(4 * (xs->n_sites + 1) + 2) * sizeof(int) + (size_t)2 * xs->n_sites * sizeof(long long);
   if (lds_ring > 80 * 1024) return fail(QK_EINVAL, "qk_gram_values: %d sites need %zu bytes of LDS per workgroup (limit 80 KiB for 2 workgroups per CU)", xs->n_sites, lds_ring);
-  if (f32) {  // complex64 sweep: the ring kernel on fp32 planes; QK_VARIANT does not apply
+  if (quad) {  // 2x2 blocks of pairs per workgroup (QK_PLAN_QUADS plans; experimental kernel in qk_lab.hip), either precision
+    const int rc_quad = qk_lab_launch_quad(c, a, grid, xs->n_sites, f32);
+    if (rc_quad != QK_OK) return rc_quad;
+  } else if (f32) {  // complex64 sweep: the ring kernel on fp32 planes; QK_VARIANT does not apply
     qk_sweep_ring_kernel<float><<<dim3(grid), dim3(512), lds_ring, c->stream>>>(a);
   } else if (c->variant == 20) {  // the shipped kernel: LDS-DMA staging ring (K-tile 8, three slots) + 3M complex product
     qk_sweep_ring_kernel<double><<<dim3(grid), dim3(512), lds_ring, c->stream>>>(a);

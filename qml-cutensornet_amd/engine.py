@@ -17,6 +17,7 @@ LIB_PATH = os.path.join(_HERE, "libqkgram.so")
 
 QK_LAYOUT_LPR, QK_LAYOUT_LRP = 0, 1
 QK_PLAN_SYMMETRIC = 1
+QK_PLAN_QUADS = 2  # 2x2 blocks of pairs per workgroup (include/qkgram.h)
 
 
 class QkError(RuntimeError):
@@ -144,7 +145,7 @@ def pack_state(mps, layout=QK_LAYOUT_LPR):
 class Plan:
     """Ordered share of the Gram's (x, y) pairs for one rank (host object)."""
 
-    def __init__(self, x_dims, y_dims=None, world_size=1, rank=0, block=0):
+    def __init__(self, x_dims, y_dims=None, world_size=1, rank=0, block=0, quads=False):
         L = lib()
         xd = np.ascontiguousarray(x_dims, dtype=np.int32)
         self.symmetric = y_dims is None
@@ -156,12 +157,12 @@ class Plan:
         _check(
             L.qk_plan_create(
                 n_sites, self.nx, xd.ctypes.data, self.ny, None if yd is None else yd.ctypes.data,
-                QK_PLAN_SYMMETRIC if self.symmetric else 0, world_size, rank, block, C.byref(h),
+                (QK_PLAN_SYMMETRIC if self.symmetric else 0) | (QK_PLAN_QUADS if quads else 0), world_size, rank, block, C.byref(h),
             ),
             "qk_plan_create",
         )
         self._h = h
-        self.world_size, self.rank = world_size, rank
+        self.world_size, self.rank, self.quads = world_size, rank, bool(quads)
 
     @property
     def handle(self):

@@ -23,14 +23,15 @@ class GramJob:
         self.ctx, self.xset, self.yset = ctx, xset, yset
         self.world, self.rank, self.group = int(world_size), int(rank), group
         self.symmetric = yset is None
-        if block is None:
-            import os
+        import os
 
+        if block is None:
             block = int(os.environ.get("QK_PLAN_BLOCK", "0"))  # 0 = no locality tiles: one global cost order
         self.nx = len(xset)
         self.ny = self.nx if self.symmetric else len(yset)
         ydims = None if self.symmetric else yset.dims
-        self.plan = engine.Plan(xset.dims, ydims, self.world, self.rank, block)
+        quads = os.environ.get("QK_QUADS", "0") == "1"  # 2x2 pair blocks per workgroup (QK_PLAN_QUADS)
+        self.plan = engine.Plan(xset.dims, ydims, self.world, self.rank, block, quads)
         self.maxp = max(1, self.plan.max_pairs_per_rank)
         dev = torch.device("cuda", ctx.device_id)
         self.dev = dev
@@ -38,7 +39,7 @@ class GramJob:
         table = np.full((self.world, self.maxp, 2), -1, dtype=np.int32)
         self.work = []
         for r in range(self.world):
-            p = self.plan if r == self.rank else engine.Plan(xset.dims, ydims, self.world, r, block)
+            p = self.plan if r == self.rank else engine.Plan(xset.dims, ydims, self.world, r, block, quads)
             pr = p.pairs()
             table[r, : pr.shape[0]] = pr
             self.work.append(p.stats())

@@ -338,3 +338,31 @@ def test_f32_gram_of_ansatz_states(gpu_ctx):
     assert np.abs(K32 - K64).max() < F32_TOL
     assert np.abs(np.diag(K32) - 1).max() < F32_TOL
     assert np.abs(K32 - K32.T).max() == 0.0
+
+
+# ------------------------------------------------------------------ 2x2 pair blocks (QK_PLAN_QUADS)
+@pytest.mark.parametrize("n,chi_max,nx,ny,seed", [(6, 4, 3, 2, 1), (14, 40, 4, 5, 3), (16, 100, 3, 4, 4), (18, 150, 5, 2, 5)])
+def test_quad_plan_matches_oracle(gpu_ctx, n, chi_max, nx, ny, seed):
+    import qml_cutensornet_amd as Q
+    from qml_cutensornet_amd import engine
+    from oracle import restatement as R
+
+    rng = np.random.default_rng(seed)
+    xs = [Q.random_mps(n, _ragged_profile(rng, n, chi_max), rng) for _ in range(nx)]
+    ys = [Q.random_mps(n, _ragged_profile(rng, n, chi_max), rng) for _ in range(ny)]
+    z_ref = np.array([[R.mps_inner(x.tensors, y.tensors) for x in xs] for y in ys])
+    zs_ref = np.array([[R.mps_inner(x.tensors, y.tensors) for x in xs] for y in xs])
+    with gpu_ctx.upload(xs) as dx, gpu_ctx.upload(ys) as dy:
+        for sym in (False, True):
+            plan = engine.Plan(dx.dims, None if sym else dy.dims, quads=True)
+            vals, z = gpu_ctx.gram_values_host(dx, None if sym else dy, plan, want_z=True)
+            ref = zs_ref if sym else z_ref
+            for (i, j), v, zz in zip(plan.pairs().tolist(), vals, z):
+                assert abs(zz - ref[j, i]) < TOL and abs(v - abs(ref[j, i]) ** 2) < TOL
+            plan.close()
+        with dx.to_f32() as fx, dy.to_f32() as fy:  # the quad kernel in complex64
+            plan = engine.Plan(dx.dims, dy.dims, quads=True)
+            vals, z = gpu_ctx.gram_values_host(fx, fy, plan, want_z=True)
+            for (i, j), zz in zip(plan.pairs().tolist(), z):
+                assert abs(zz - z_ref[j, i]) < F32_TOL
+            plan.close()

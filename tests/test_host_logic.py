@@ -224,6 +224,41 @@ def test_plan_partitions_the_gram(built, world, symmetric):
         assert max(costs) / np.mean(costs) < 1.2  # the deal balances work, not only counts
 
 
+@pytest.mark.parametrize("world", [1, 3])
+@pytest.mark.parametrize("symmetric", [True, False])
+@pytest.mark.parametrize("nx", [7, 10])
+def test_quad_plan_covers_the_gram(built, world, symmetric, nx):
+    """QK_PLAN_QUADS: 2x2 blocks {i1,i2} x {j1,j2}; every wanted entry appears, duplicates only where documented
+    (odd sets repeat the last state, symmetric diagonal blocks hold one mirrored pair), flops count each entry once."""
+    from qml_cutensornet_amd import engine
+
+    rng = np.random.default_rng(nx + world)
+    ny, n = 5, 9
+    xd = np.ones((nx, n + 1), dtype=np.int32)
+    yd = np.ones((ny, n + 1), dtype=np.int32)
+    xd[:, 1:-1] = rng.integers(1, 70, size=(nx, n - 1))
+    yd[:, 1:-1] = rng.integers(1, 70, size=(ny, n - 1))
+    seen = set()
+    flops = 0.0
+    for r in range(world):
+        p = engine.Plan(xd, None if symmetric else yd, world, r, quads=True)
+        pr = p.pairs()
+        assert len(pr) % 4 == 0 and p.num_pairs == len(pr)
+        for q in range(len(pr) // 4):
+            (i1, j1), (i2, j1b), (i1b, j2), (i2b, j2b) = pr[4 * q : 4 * q + 4].tolist()
+            assert (i1, i2, j1, j2) == (i1b, i2b, j1b, j2b)  # block order (i1,j1) (i2,j1) (i1,j2) (i2,j2)
+            assert i2 in (i1, i1 + 1) and j2 in (j1, j1 + 1) and i1 % 2 == 0 and j1 % 2 == 0
+        for i, j in pr.tolist():
+            seen.add((min(i, j), max(i, j)) if symmetric else (i, j))
+        flops += p.stats()["flops"]
+        p.close()
+    want = {(i, j) for j in range(nx if symmetric else ny) for i in range(nx) if (not symmetric or i <= j)}
+    assert seen == want
+    ref = engine.Plan(xd, None if symmetric else yd)
+    assert flops == pytest.approx(ref.stats()["flops"], rel=1e-12)
+    ref.close()
+
+
 def test_default_plan_balances_rank_shares(built):
     """Default planner (no locality tiles, serpentine deal over the global cost order): the flops of the
     rank shares of a ragged 200-state symmetric Gram agree within 1 % for 2..8 ranks."""
