@@ -297,6 +297,8 @@ def main():
                 "frac": achieved / peak,
                 "traffic": traffic,
                 "traffic_source": "profiles/r01/pmc_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, FETCH_SIZE x2 gfx950 correction), bytes per launch" if traffic else None,
+                # L2<->fabric rate those bytes imply at this run's kernel time (Infinity-Cache hits included; HBM peak ~8 TB/s)
+                "traffic_tb_per_s": (traffic / (kms * 1e-3) / 1e12) if (traffic and kms > 0) else None,
                 "kernel_ms": kms,
                 "algorithmic_tflop_per_launch": my["flops"] / 1e12,
                 # the same count with every bond rounded up to the 16-wide MFMA tile (four-product form); the shipped kernel
