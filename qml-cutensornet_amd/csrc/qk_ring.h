@@ -376,3 +376,200 @@ __global__ __launch_bounds__(512, 4) void qk_sweep_ring_kernel(const SweepArgs g
     __syncthreads();
   }
 }
+
+// ----------------------------------------------------------------------------------------
+// Small-bond sweep: every (padded) bond of both sets is <= 32, so the environment X (<= 32 x 32) and the
+// intermediate T (<= 32 x 64) of a pair live in LDS for the whole chain -- no global scratch, no store drain, no
+// write->read round trip.  The ONLY global traffic is the site tensors, and because they depend on nothing they are
+// fetched as ONE flat stream of K-tiles for the whole pair,
+//     B_0 tiles | A_0 tiles | B_1 tiles | A_1 tiles | ...       (B_k: K = b_k rows of [2b'],  A_k: K = 2a_k rows of [a'])
+// by LDS-DMA into a three-slot ring, two tiles ahead of the MFMAs, across GEMM and site boundaries.  A GEMM has at
+// most 8 output tiles: wave w owns tile w (3M product, as in the ring GEMM); its result goes back to LDS in the
+// k-major layout the next GEMM reads as its A operand.  Used automatically when both sets qualify (QK_SMALL=0 opts out).
+// This is the regime of the reference's own runs (gamma = 0.1 ... 0.5: bonds 2 ... 34).
+// ----------------------------------------------------------------------------------------
+// The pair's tile stream (fetch side) and ring position (compute side) of the small-bond sweep.
+template <typename T>
+struct QkSmallStream {
+  typedef __attribute__((address_space(3))) void* lds_ptr_t;
+  static constexpr int NSLOT = 3;
+  static constexpr int KTL = 64 / (int)sizeof(T);  // K rows per stream tile: 8 (double) / 16 (float): 4 KiB per plane
+  static constexpr int KS = KTL / 4;
+  static constexpr int EPL = 16 / (int)sizeof(T), CHUNK = 1024 / (int)sizeof(T), RPC = CHUNK / 64, LPR = 64 / RPC;
+  static constexpr int BPL = KTL * 64, SLOT = 2 * BPL;  // slot: B re | B im planes of [KTL][64]
+  // constants of the pair / lane
+  const T *xdata, *ydata;
+  const int *m_xd, *m_yd, *m_xt, *m_yt;
+  const long long *m_xo, *m_yo;
+  T *ring, *dst0;
+  int ns, pl, srow, scol;
+  // fetch state
+  int f_site, f_which, f_left, f_slot, issued;
+  bool f_more;
+  const T* f_ptr;
+  unsigned f_off;
+  long long f_step;
+  // compute state
+  int consumed, c_slot;
+
+  static __device__ __forceinline__ int ldi(const int* q_) { return __builtin_amdgcn_readfirstlane(*q_); }
+  static __device__ __forceinline__ long long ldl(const long long* q_) {
+    const long long v = *q_;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v);
+    const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)((unsigned long long)v >> 32));
+    return (long long)(((unsigned long long)hi << 32) | lo);
+  }
+  __device__ __forceinline__ void open_segment() {  // (f_site, f_which) -> this wave's plane pointer, row stride, tile count
+    const int a = ldi(m_xd + f_site), an = ldi(m_xd + f_site + 1), b = ldi(m_yd + f_site), bn = ldi(m_yd + f_site + 1);
+    int ld, ktrue;
+    const T* base;
+    if (f_which == 0) {  // B_k as [b][2 b']
+      ld = 2 * bn, ktrue = ldi(m_yt + f_site);
+      base = ydata + ldl(m_yo + f_site) + (pl ? (long long)b * 2 * bn : 0);
+    } else {  // A_k as [(a, p)][a']
+      ld = an, ktrue = 2 * ldi(m_xt + f_site);
+      base = xdata + ldl(m_xo + f_site) + (pl ? (long long)a * 2 * an : 0);
+    }
+    f_ptr = base;
+    f_off = (unsigned)(srow * ld + min(scol, ld - EPL));
+    f_step = (long long)KTL * ld;
+    f_left = (ktrue + KTL - 1) / KTL;
+  }
+  __device__ __forceinline__ void fetch() {
+    __builtin_amdgcn_global_load_lds(f_ptr + f_off, (lds_ptr_t)(dst0 + f_slot), 16, 0, 0);
+    ++issued;
+    f_ptr += f_step;
+    f_slot = (f_slot == (NSLOT - 1) * SLOT) ? 0 : f_slot + SLOT;
+    if (--f_left == 0) {
+      if (f_which == 0) f_which = 1;
+      else f_which = 0, ++f_site;
+      if (f_site < ns) open_segment();
+      else f_more = false;
+    }
+  }
+  __device__ __forceinline__ void start() {
+    f_site = f_which = f_slot = issued = consumed = c_slot = 0;
+    f_more = true;
+    open_segment();
+    fetch();
+    if (f_more) fetch();
+    asm volatile("s_waitcnt vmcnt(1)" ::: "memory");  // tile 0 landed (tile 1 may still fly); a chain has >= 2 tiles
+    qk_lds_barrier();
+  }
+};
+
+// C[M x N] (LDS planes cpl apart, ld ldc) = sum_k Aop[k][m] * Bstream[k][n]: Aop resident in LDS (planes apl apart, ld lda),
+// K-tiles taken from the stream.  At most 8 output tiles: wave w owns tile w.
+template <bool CONJB, typename T>
+__device__ __forceinline__ void qk_small_gemm(QkSmallStream<T>& st, T* Cre, const int cpl, const int ldc, const T* Are, const int apl,
+                                              const int lda, const int M, const int N, const int Ktrue) {
+  using S = QkScalar<T>;
+  using V4 = typename S::v4;
+  using ST = QkSmallStream<T>;
+  constexpr int KTL = ST::KTL, KS = ST::KS, BPL = ST::BPL;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int j = lane & 15, q = lane >> 4;
+  const int mt = M / TILE, nt = N / TILE;
+  const bool mine = wave < mt * nt;
+  const int tm = mine ? wave % mt : 0, tn = mine ? wave / mt : 0;
+  const int nk = (Ktrue + KTL - 1) / KTL;
+  const int ks_last = ((Ktrue + 3) >> 2) - (nk - 1) * KS;
+  V4 c1 = {0, 0, 0, 0}, c2 = {0, 0, 0, 0}, c3 = {0, 0, 0, 0};
+  const int la = q * lda + tm * TILE + j;
+  const int lb = q * 64 + tn * TILE + j;
+  for (int kt = 0; kt < nk; ++kt) {
+    if (st.f_more) st.fetch();  // two tiles ahead of this one
+    if (mine) {
+      const T* pa = Are + (long long)kt * KTL * lda + la;
+      const T* pb = st.ring + st.c_slot + lb;
+      const int ksteps = (kt + 1 < nk) ? KS : ks_last;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        if (ks < ksteps) mma3_kstep<CONJB, true, T>(c1, c2, c3, pa[4 * ks * lda], pa[apl + 4 * ks * lda], pb[4 * ks * 64], pb[BPL + 4 * ks * 64]);
+      }
+    }
+    ++st.consumed;
+    // the next tile of the stream (possibly the next GEMM's first) must have landed; the one after it may still fly
+    if (st.issued - st.consumed >= 2) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    qk_lds_barrier();
+    st.c_slot = (st.c_slot == (ST::NSLOT - 1) * ST::SLOT) ? 0 : st.c_slot + ST::SLOT;
+  }
+  if (mine) {
+    T* cr = Cre + (tm * TILE + S::ROW_Q * q) * ldc + tn * TILE + j;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const T p1 = c1[r], p2 = c2[r], p3 = c3[r];
+      cr[r * S::ROW_R * ldc] = CONJB ? p1 + p2 : p1 - p2;
+      cr[cpl + r * S::ROW_R * ldc] = CONJB ? (p3 - p1) + p2 : (p3 - p1) - p2;
+    }
+  }
+  qk_lds_barrier();  // C complete for every wave before the next GEMM reads it as its A operand
+}
+
+template <typename T>
+__global__ __launch_bounds__(512, 4) void qk_sweep_small_kernel(const SweepArgs g) {
+  using ST = QkSmallStream<T>;
+  constexpr int NW = 8, MAXB = 32;
+  extern __shared__ __attribute__((aligned(16))) double lds_raw[];
+  T* const ring = reinterpret_cast<T*>(lds_raw);                 // NSLOT * SLOT elements (24 KiB)
+  T* const XS = ring + ST::NSLOT * ST::SLOT;                      // X: re | im planes, MAXB * MAXB each
+  T* const TS = XS + 2 * MAXB * MAXB;                             // T: re | im planes, MAXB * 2 MAXB each
+  long long* const slot = reinterpret_cast<long long*>(TS + 4 * MAXB * MAXB);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  QkSmallStream<T> st;
+  st.xdata = reinterpret_cast<const T*>(g.xdata);
+  st.ydata = reinterpret_cast<const T*>(g.ydata);
+  st.ring = ring;
+  st.ns = g.n_sites;
+  st.pl = wave >> 2;  // staging role: plane wave >> 2 (re / im), piece wave & 3 of the tile
+  st.srow = ST::RPC * (wave & 3) + lane / ST::LPR;
+  st.scol = (lane % ST::LPR) * ST::EPL;
+  st.dst0 = ring + st.pl * ST::BPL + (wave & 3) * ST::CHUNK;
+  for (;;) {
+    if (tid == 0) *slot = (long long)atomicAdd(g.counter, 1ull);
+    __syncthreads();
+    const long long p = *slot;
+    __syncthreads();
+    if (p >= g.npairs) break;
+    const int xi = g.pairs[2 * p], yj = g.pairs[2 * p + 1];
+    const int n1 = g.n_sites + 1, ns = g.n_sites;
+    int* m_xd = reinterpret_cast<int*>(slot + 2);
+    int* m_yd = m_xd + n1;
+    int* m_xt = m_yd + n1;
+    int* m_yt = m_xt + n1;
+    long long* m_xo = reinterpret_cast<long long*>(m_xd + 4 * n1 + (4 * n1 & 1));
+    long long* m_yo = m_xo + ns;
+    for (int e = tid; e < n1; e += 64 * NW) {
+      m_xd[e] = g.xdims[(long long)xi * n1 + e];
+      m_yd[e] = g.ydims[(long long)yj * n1 + e];
+      m_xt[e] = g.xtrue[(long long)xi * n1 + e];
+      m_yt[e] = g.ytrue[(long long)yj * n1 + e];
+      if (e < ns) {
+        m_xo[e] = g.xoffs[(long long)xi * ns + e];
+        m_yo[e] = g.yoffs[(long long)yj * ns + e];
+      }
+    }
+    for (int e = tid; e < 2 * MAXB * MAXB; e += 64 * NW) XS[e] = (e == 0) ? (T)1 : (T)0;  // X_0 = 1 (ld = 16: [0][0])
+    __syncthreads();
+    st.m_xd = m_xd, st.m_yd = m_yd, st.m_xt = m_xt, st.m_yt = m_yt, st.m_xo = m_xo, st.m_yo = m_yo;
+    st.start();
+    for (int k = 0; k < ns; ++k) {
+      const int a = ST::ldi(m_xd + k), an = ST::ldi(m_xd + k + 1), bn = ST::ldi(m_yd + k + 1);
+      // T [a x 2b'] = X^T B_k ;  X' [b' x a'] = T^T conj(A_k)  (T re-read as [(a, p)][b'])
+      qk_small_gemm<false, T>(st, TS, 2 * MAXB * MAXB, 2 * bn, XS, MAXB * MAXB, a, a, 2 * bn, ST::ldi(m_yt + k));
+      qk_small_gemm<true, T>(st, XS, MAXB * MAXB, an, TS, 2 * MAXB * MAXB, bn, bn, an, 2 * ST::ldi(m_xt + k));
+    }
+    if (tid == 0) {
+      const double re = (double)XS[0], im = (double)XS[MAXB * MAXB];
+      g.values[p] = re * re + im * im;
+      if (g.z) {
+        g.z[2 * p] = re;
+        g.z[2 * p + 1] = im;
+      }
+    }
+    __syncthreads();
+  }
+}

@@ -352,11 +352,14 @@ extern "C" int qk_ctx_create(int device_id, qk_ctx** out) {
   HIP_TRY(hipMemset(c->prof, 0, 8 * sizeof(unsigned long long)));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(qk_sweep_ring_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(qk_sweep_ring_kernel<double>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(qk_sweep_small_kernel<double>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(qk_sweep_small_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
   {
     const int rc = qk_lab_init(c);
     if (rc != QK_OK) return rc;
   }
   if (const char* v = std::getenv("QK_VARIANT")) c->variant = std::atoi(v);
+  if (const char* v = std::getenv("QK_SMALL")) c->small_path = std::atoi(v) != 0;
   if (const char* v = std::getenv("QK_WGS_PER_CU")) c->wgs_per_cu = std::max(1, std::min(4, std::atoi(v)));
   *out = c;
   return QK_OK;
@@ -587,6 +590,13 @@ extern "C" int qk_gram_values(qk_ctx* c, const qk_mps_set* xs, const qk_mps_set*
   if (quad) {  // 2x2 blocks of pairs per workgroup (QK_PLAN_QUADS plans; experimental kernel in qk_lab.hip), either precision
     const int rc_quad = qk_lab_launch_quad(c, a, grid, xs->n_sites, f32);
     if (rc_quad != QK_OK) return rc_quad;
+  } else if (c->variant == 20 && c->small_path && std::max(xs->max_pad, ys->max_pad) <= 32) {
+    // every bond <= 32: X and T stay in LDS, only the site tensors stream (qk_sweep_small_kernel)
+    const size_t esz = f32 ? sizeof(float) : sizeof(double);
+    const size_t lds_small = (size_t)(3 * 2 * (64 / esz) * 64 + 6 * 32 * 32) * esz + 16 + (size_t)(4 * (xs->n_sites + 1) + 2) * sizeof(int) + (size_t)2 * xs->n_sites * sizeof(long long);
+    if (lds_small > 80 * 1024) return fail(QK_EINVAL, "qk_gram_values: %d sites need %zu bytes of LDS per workgroup (limit 80 KiB for 2 workgroups per CU)", xs->n_sites, lds_small);
+    if (f32) qk_sweep_small_kernel<float><<<dim3(grid), dim3(512), lds_small, c->stream>>>(a);
+    else qk_sweep_small_kernel<double><<<dim3(grid), dim3(512), lds_small, c->stream>>>(a);
   } else if (f32) {  // complex64 sweep: the ring kernel on fp32 planes; QK_VARIANT does not apply
     qk_sweep_ring_kernel<float><<<dim3(grid), dim3(512), lds_ring, c->stream>>>(a);
   } else if (c->variant == 20) {  // the shipped kernel: LDS-DMA staging ring (K-tile 8, three slots) + 3M complex product

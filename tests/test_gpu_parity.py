@@ -366,3 +366,30 @@ def test_quad_plan_matches_oracle(gpu_ctx, n, chi_max, nx, ny, seed):
             for (i, j), zz in zip(plan.pairs().tolist(), z):
                 assert abs(zz - z_ref[j, i]) < F32_TOL
             plan.close()
+
+
+# ------------------------------------------------------------------ small-bond sweep (all bonds <= 32: X, T resident in LDS)
+@pytest.mark.parametrize("n,chi_max,nx,ny,seed", [(5, 2, 3, 3, 1), (24, 16, 4, 3, 2), (40, 32, 5, 4, 3), (100, 27, 3, 3, 4)])
+def test_small_bond_kernel(gpu_ctx, n, chi_max, nx, ny, seed, monkeypatch):
+    import qml_cutensornet_amd as Q
+    from qml_cutensornet_amd import engine
+    from oracle import restatement as R
+
+    rng = np.random.default_rng(seed)
+    xs = [Q.random_mps(n, _ragged_profile(rng, n, chi_max), rng) for _ in range(nx)]
+    ys = [Q.random_mps(n, _ragged_profile(rng, n, chi_max), rng) for _ in range(ny)]
+    z_ref = np.array([[R.mps_inner(x.tensors, y.tensors) for x in xs] for y in ys])
+    with gpu_ctx.upload(xs) as dx, gpu_ctx.upload(ys) as dy:
+        assert max(dx.info()["max_padded_bond"], dy.info()["max_padded_bond"]) <= 32  # takes the small-bond path
+        z = gpu_ctx.overlaps(dx, dy)
+        K = gpu_ctx.gram(dx)
+        with dx.to_f32() as fx, dy.to_f32() as fy:
+            z32 = gpu_ctx.overlaps(fx, fy)
+    assert np.abs(z - z_ref).max() < TOL
+    assert np.abs(np.diag(K) - 1).max() < 1e-12 and np.abs(K - K.T).max() == 0.0
+    assert np.abs(z32 - z_ref).max() < F32_TOL
+    # the general (ring) kernel on the same inputs agrees to rounding
+    monkeypatch.setenv("QK_SMALL", "0")
+    with engine.context(0) as ctx2, ctx2.upload(xs) as dx2, ctx2.upload(ys) as dy2:
+        z_ring = ctx2.overlaps(dx2, dy2)
+    assert np.abs(z - z_ring).max() < 1e-13

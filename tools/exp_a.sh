@@ -1,11 +1,10 @@
 #!/bin/bash
 export QK_CACHE_DIR=/tmp/qkc
 mkdir -p gpurun_out
-timeout -k 10 900 python bench.py --config cfg5 --cpu-seconds 0 --steps 2 --precision f32 > gpurun_out/b5_32.json 2> gpurun_out/b5_32.err || tail -5 gpurun_out/b5_32.err
-timeout -k 10 600 python bench.py --config cfg3 --cpu-seconds 0 --steps 2 --precision f32 > gpurun_out/b3_32.json 2> gpurun_out/b3_32.err || tail -5 gpurun_out/b3_32.err
-python - <<PY
-import json
-for f in ("b5_32","b3_32"):
-    d=json.loads(open("gpurun_out/%s.json"%f).read().strip().splitlines()[-1])
-    print(f, d["dtype"], "ms %.1f kernel %.1f frac %.4f value %.0f"%(d["ms_per_step"], d["roofline"]["kernel_ms"], d["roofline"]["frac"], d["value"]), {k:v for k,v in d["config"].items() if k.startswith("f32") or k in ("diag_err","max_bond_max")})
-PY
+echo "== gpu suite"
+timeout -k 10 600 python -m pytest tests -m gpu -x -q 2>&1 | tail -8
+echo "== chi scan small"
+for sm in 1 0; do QK_SMALL=$sm QK_CHIS=2,8,16,24,32 timeout -k 10 300 python tools/chi_scan.py 60 181 2>&1 | grep -v amdgpu.ids; done
+echo "== cfg5 / cfg2"
+for sm in 1 0; do for c in cfg5 cfg2; do QK_SMALL=$sm timeout -k 10 600 python bench.py --config $c --cpu-seconds 0 --steps 2 > gpurun_out/bs_${c}_$sm.json 2> gpurun_out/bs_${c}_$sm.err || tail -3 gpurun_out/bs_${c}_$sm.err; python -c "
+import json; d=json.loads(open('gpurun_out/bs_${c}_$sm.json').read().strip().splitlines()[-1]); print('$c small=$sm', 'ms %.2f value %.0f diag_err %.1e'%(d['ms_per_step'], d['value'], d['config']['diag_err']))"; done; done
