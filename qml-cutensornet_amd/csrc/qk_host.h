@@ -33,6 +33,7 @@ struct qk_ctx {
   int variant = 20;    // sweep kernel variant (QK_VARIANT): 20 = shipped (ring sweep: LDS-DMA ring + 3M product); 17 = lean register-staged sweep;
                        // 0, 2, 12, 13, 14, 16, 21, 23 = other kernels kept for A/B; 9, 19 = instrumented
   int wgs_per_cu = 2;  // resident workgroups per CU (QK_WGS_PER_CU)
+  bool wave_path = true;   // fp64 sets whose bonds are all <= 16 use the one-wave-per-pair register sweep (QK_WAVE=0 opts out)
   bool small_path = true;  // sets whose bonds are all <= 32 use the LDS-resident small-bond sweep (QK_SMALL=0 opts out)
   qk_stats last{};
 };

@@ -573,3 +573,98 @@ __global__ __launch_bounds__(512, 4) void qk_sweep_small_kernel(const SweepArgs 
     __syncthreads();
   }
 }
+
+// ----------------------------------------------------------------------------------------
+// Wave sweep: every (padded) bond of both sets is 16 -- every matrix of the chain is one 16x16 tile (T: two), and a
+// whole pair fits in the registers of ONE wavefront.  No LDS, no barrier, no scratch: each wave pulls its own pairs.
+// It rests on a property of v_mfma_f64_16x16x4_f64: its C/D layout (register r of lane (q, j) = C[q + 4r][j]) IS the
+// A-operand layout of a k-major operand (k-step ks of lane (q, j) = Aop[4 ks + q][j]) with r = ks.  So
+//     T_p [a x b'] = X^T . B_k[:, p, :]                  (p = 0, 1: two output tiles, A operand = the X registers)
+//     X'  [b' x a'] = sum_p T_p^T . conj(A_k[:, p, :])    (A operand = the T_p result registers, K = a per p)
+// chain through registers with no data movement at all; the site tensors are read straight into B fragments
+// (lane (q, j) of k-step ks and block p reads element [(4 ks + q)][p][j] of the [chi][2][16] tensor: 128-byte rows),
+// only the k-steps below the TRUE bond.  This is the regime of the reference's runs at gamma = 0.1 (bonds 2 ... 8).
+// fp64 only (the f32 MFMA's C layout is C[4q + r][j], which is not an operand layout).
+// ----------------------------------------------------------------------------------------
+static __device__ __forceinline__ void qk_wave_3m(v4d& p1, v4d& p2, v4d& p3, const double ar, const double ai, const double br, const double bi, const bool conjb) {
+  const double sa = ar + ai, sb = conjb ? br - bi : br + bi;
+  p1 = __builtin_amdgcn_mfma_f64_16x16x4f64(ar, br, p1, 0, 0, 0);
+  p2 = __builtin_amdgcn_mfma_f64_16x16x4f64(ai, bi, p2, 0, 0, 0);
+  p3 = __builtin_amdgcn_mfma_f64_16x16x4f64(sa, sb, p3, 0, 0, 0);
+}
+
+static __device__ __forceinline__ int uni_i(const int v) { return __builtin_amdgcn_readfirstlane(v); }
+static __device__ __forceinline__ long long uni_ll(const long long v) {
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v);
+  const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)((unsigned long long)v >> 32));
+  return (long long)(((unsigned long long)hi << 32) | lo);
+}
+
+template <int UNUSED = 0>  // a template only so that both translation units may include this header
+__global__ __launch_bounds__(64, 4) void qk_sweep_wave_kernel(const SweepArgs g) {  // ONE wave per workgroup
+  __shared__ long long slot;
+  const int lane = threadIdx.x;
+  const int j = lane & 15, q = lane >> 4;
+  const int ns = g.n_sites, n1 = ns + 1;
+  const int foff = q * 32 + j;  // this lane's element of k-step 0, block 0 in a [16][2][16] plane
+  for (;;) {
+    if (lane == 0) slot = (long long)atomicAdd(g.counter, 1ull);
+    __syncthreads();
+    const long long p = uni_ll(slot);  // every per-pair / per-site scalar is made provably wave-uniform: the k-step
+    __syncthreads();                   // guards below must be scalar branches around the MFMAs
+    if (p >= g.npairs) break;
+    const int xi = uni_i(g.pairs[2 * p]), yj = uni_i(g.pairs[2 * p + 1]);
+    const int* xt = g.xtrue + (long long)xi * n1;
+    const int* yt = g.ytrue + (long long)yj * n1;
+    const int64_t* xo = g.xoffs + (long long)xi * ns;
+    const int64_t* yo = g.yoffs + (long long)yj * ns;
+    // X as A-operand fragments: k-step ks of lane (q, j) = X[4 ks + q][j];  X_0 = 1 at [0][0]
+    v4d xr = {(lane == 0) ? 1.0 : 0.0, 0, 0, 0}, xim = {0, 0, 0, 0};
+    for (int k = 0; k < ns; ++k) {
+      const int ksb = (uni_i(yt[k]) + 3) >> 2, ksa = (uni_i(xt[k]) + 3) >> 2;  // k-steps below the true bonds b_k and a_k (1..4)
+      const double* Bre = g.ydata + uni_ll(yo[k]) + foff;  // B_k: [b][2][b'] planes of 512 doubles
+      const double* Are = g.xdata + uni_ll(xo[k]) + foff;  // A_k: [a][2][a']
+      // ---- T_p = X^T B_k[:, p, :]
+      v4d tr[2], ti[2];
+#pragma unroll
+      for (int pp = 0; pp < 2; ++pp) {
+        v4d p1 = {0, 0, 0, 0}, p2 = {0, 0, 0, 0}, p3 = {0, 0, 0, 0};
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+          if (ks < ksb) {
+            const double br = Bre[ks * 128 + pp * 16], bi = Bre[512 + ks * 128 + pp * 16];
+            qk_wave_3m(p1, p2, p3, xr[ks], xim[ks], br, bi, false);
+          }
+        }
+        tr[pp] = p1 - p2;
+        ti[pp] = p3 - p1 - p2;
+      }
+      // ---- X' = sum_p T_p^T conj(A_k[:, p, :])
+      v4d p1 = {0, 0, 0, 0}, p2 = {0, 0, 0, 0}, p3 = {0, 0, 0, 0};
+#pragma unroll
+      for (int pp = 0; pp < 2; ++pp) {
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+          if (ks < ksa) {
+            const double ar = Are[ks * 128 + pp * 16], ai = Are[512 + ks * 128 + pp * 16];
+            qk_wave_3m(p1, p2, p3, tr[pp][ks], ti[pp][ks], ar, ai, true);
+          }
+        }
+      }
+      xr = p1 + p2;
+      xim = p3 - p1 + p2;
+    }
+    {
+      // z = X_n[0][0] sits in lane 0.  It is broadcast and stored by every lane (one coalesced write): a lane-0-only
+      // block at the end of this barrier-free loop makes hipcc (ROCm 7.2) structurise the pair loop as a divergent loop
+      // that only lane 0 leaves -- the other 63 lanes then re-run the same pair for ever.
+      const double re = __longlong_as_double(uni_ll(__double_as_longlong(xr[0])));
+      const double im = __longlong_as_double(uni_ll(__double_as_longlong(xim[0])));
+      g.values[p] = re * re + im * im;
+      if (g.z) {
+        g.z[2 * p] = re;
+        g.z[2 * p + 1] = im;
+      }
+    }
+  }
+}

@@ -360,6 +360,7 @@ extern "C" int qk_ctx_create(int device_id, qk_ctx** out) {
   }
   if (const char* v = std::getenv("QK_VARIANT")) c->variant = std::atoi(v);
   if (const char* v = std::getenv("QK_SMALL")) c->small_path = std::atoi(v) != 0;
+  if (const char* v = std::getenv("QK_WAVE")) c->wave_path = std::atoi(v) != 0;
   if (const char* v = std::getenv("QK_WGS_PER_CU")) c->wgs_per_cu = std::max(1, std::min(4, std::atoi(v)));
   *out = c;
   return QK_OK;
@@ -590,6 +591,11 @@ extern "C" int qk_gram_values(qk_ctx* c, const qk_mps_set* xs, const qk_mps_set*
   if (quad) {  // 2x2 blocks of pairs per workgroup (QK_PLAN_QUADS plans; experimental kernel in qk_lab.hip), either precision
     const int rc_quad = qk_lab_launch_quad(c, a, grid, xs->n_sites, f32);
     if (rc_quad != QK_OK) return rc_quad;
+  } else if (c->variant == 20 && c->wave_path && !f32 && std::max(xs->max_pad, ys->max_pad) <= 16) {
+    // every bond <= 16: a pair lives in the registers of one wavefront (qk_sweep_wave_kernel); 16 waves per CU
+    const int wgrid = (int)std::min<long long>(np, 16ll * c->num_cus);
+    qk_sweep_wave_kernel<0><<<dim3(wgrid), dim3(64), 0, c->stream>>>(a);
+    c->last.grid = wgrid;
   } else if (c->variant == 20 && c->small_path && std::max(xs->max_pad, ys->max_pad) <= 32) {
     // every bond <= 32: X and T stay in LDS, only the site tensors stream (qk_sweep_small_kernel)
     const size_t esz = f32 ? sizeof(float) : sizeof(double);

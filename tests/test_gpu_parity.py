@@ -369,7 +369,7 @@ def test_quad_plan_matches_oracle(gpu_ctx, n, chi_max, nx, ny, seed):
 
 
 # ------------------------------------------------------------------ small-bond sweep (all bonds <= 32: X, T resident in LDS)
-@pytest.mark.parametrize("n,chi_max,nx,ny,seed", [(5, 2, 3, 3, 1), (24, 16, 4, 3, 2), (40, 32, 5, 4, 3), (100, 27, 3, 3, 4)])
+@pytest.mark.parametrize("n,chi_max,nx,ny,seed", [(5, 2, 3, 3, 1), (24, 16, 4, 3, 2), (60, 9, 6, 5, 6), (40, 32, 5, 4, 3), (100, 27, 3, 3, 4)])
 def test_small_bond_kernel(gpu_ctx, n, chi_max, nx, ny, seed, monkeypatch):
     import qml_cutensornet_amd as Q
     from qml_cutensornet_amd import engine
@@ -388,7 +388,12 @@ def test_small_bond_kernel(gpu_ctx, n, chi_max, nx, ny, seed, monkeypatch):
     assert np.abs(z - z_ref).max() < TOL
     assert np.abs(np.diag(K) - 1).max() < 1e-12 and np.abs(K - K.T).max() == 0.0
     assert np.abs(z32 - z_ref).max() < F32_TOL
-    # the general (ring) kernel on the same inputs agrees to rounding
+    # the general (ring) kernel on the same inputs agrees to rounding; so does the LDS-resident kernel where the
+    # register (wave) kernel was the one selected above (bonds <= 16)
+    monkeypatch.setenv("QK_WAVE", "0")
+    with engine.context(0) as ctx1, ctx1.upload(xs) as dx1, ctx1.upload(ys) as dy1:
+        z_small = ctx1.overlaps(dx1, dy1)
+    assert np.abs(z - z_small).max() < 1e-13
     monkeypatch.setenv("QK_SMALL", "0")
     with engine.context(0) as ctx2, ctx2.upload(xs) as dx2, ctx2.upload(ys) as dy2:
         z_ring = ctx2.overlaps(dx2, dy2)
