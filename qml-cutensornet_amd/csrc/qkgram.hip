@@ -588,6 +588,8 @@ extern "C" int qk_gram_values(qk_ctx* c, const qk_mps_set* xs, const qk_mps_set*
   // per-pair site metadata in LDS behind the three ring slots: 4 (n+1) ints + 2 n int64 (+ alignment)
   const size_t lds_ring = 3 * 16 * 1024 + 16 + (size_t)(4 * (xs->n_sites + 1) + 2) * sizeof(int) + (size_t)2 * xs->n_sites * sizeof(long long);
   if (lds_ring > 80 * 1024) return fail(QK_EINVAL, "qk_gram_values: %d sites need %zu bytes of LDS per workgroup (limit 80 KiB for 2 workgroups per CU)", xs->n_sites, lds_ring);
+  const size_t esz = f32 ? sizeof(float) : sizeof(double);
+  const size_t lds_small = (size_t)(3 * 2 * (64 / esz) * 64 + 6 * 32 * 32) * esz + 16 + (size_t)(4 * (xs->n_sites + 1) + 2) * sizeof(int) + (size_t)2 * xs->n_sites * sizeof(long long);
   if (quad) {  // 2x2 blocks of pairs per workgroup (QK_PLAN_QUADS plans; experimental kernel in qk_lab.hip), either precision
     const int rc_quad = qk_lab_launch_quad(c, a, grid, xs->n_sites, f32);
     if (rc_quad != QK_OK) return rc_quad;
@@ -596,11 +598,9 @@ extern "C" int qk_gram_values(qk_ctx* c, const qk_mps_set* xs, const qk_mps_set*
     const int wgrid = (int)std::min<long long>(np, 16ll * c->num_cus);
     qk_sweep_wave_kernel<0><<<dim3(wgrid), dim3(64), 0, c->stream>>>(a);
     c->last.grid = wgrid;
-  } else if (c->variant == 20 && c->small_path && std::max(xs->max_pad, ys->max_pad) <= 32) {
-    // every bond <= 32: X and T stay in LDS, only the site tensors stream (qk_sweep_small_kernel)
-    const size_t esz = f32 ? sizeof(float) : sizeof(double);
-    const size_t lds_small = (size_t)(3 * 2 * (64 / esz) * 64 + 6 * 32 * 32) * esz + 16 + (size_t)(4 * (xs->n_sites + 1) + 2) * sizeof(int) + (size_t)2 * xs->n_sites * sizeof(long long);
-    if (lds_small > 80 * 1024) return fail(QK_EINVAL, "qk_gram_values: %d sites need %zu bytes of LDS per workgroup (limit 80 KiB for 2 workgroups per CU)", xs->n_sites, lds_small);
+  } else if (c->variant == 20 && c->small_path && std::max(xs->max_pad, ys->max_pad) <= 32 && lds_small <= 80 * 1024) {
+    // every bond <= 32: X and T stay in LDS, only the site tensors stream (qk_sweep_small_kernel); chains too long for
+    // its LDS budget (several hundred sites) take the ring kernel below
     if (f32) qk_sweep_small_kernel<float><<<dim3(grid), dim3(512), lds_small, c->stream>>>(a);
     else qk_sweep_small_kernel<double><<<dim3(grid), dim3(512), lds_small, c->stream>>>(a);
   } else if (f32) {  // complex64 sweep: the ring kernel on fp32 planes; QK_VARIANT does not apply
