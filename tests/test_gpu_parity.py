@@ -398,3 +398,27 @@ def test_small_bond_kernel(gpu_ctx, n, chi_max, nx, ny, seed, monkeypatch):
     with engine.context(0) as ctx2, ctx2.upload(xs) as dx2, ctx2.upload(ys) as dy2:
         z_ring = ctx2.overlaps(dx2, dy2)
     assert np.abs(z - z_ring).max() < 1e-13
+
+
+# ------------------------------------------------------------------ randomised sweep over shapes (all three product kernels)
+def test_randomised_shapes_against_oracle(gpu_ctx):
+    """40 seeded random (sites, bond cap, set sizes): bond caps 2...70 exercise the register (<= 16), LDS-resident (<= 32)
+    and ring kernels, ragged profiles exercise the K-trim and the partially filled passes."""
+    import qml_cutensornet_amd as Q
+    from oracle import restatement as R
+
+    rng = np.random.default_rng(2024)
+    worst = 0.0
+    for case in range(40):
+        n = int(rng.integers(2, 26))
+        chi_max = int(rng.choice([2, 3, 5, 8, 13, 16, 17, 24, 31, 32, 33, 40, 48, 64, 70]))
+        nx, ny = int(rng.integers(1, 5)), int(rng.integers(1, 5))
+        xs = [Q.random_mps(n, _ragged_profile(rng, n, chi_max), rng) for _ in range(nx)]
+        ys = [Q.random_mps(n, _ragged_profile(rng, n, chi_max), rng) for _ in range(ny)]
+        z_ref = np.array([[R.mps_inner(x.tensors, y.tensors) for x in xs] for y in ys])
+        with gpu_ctx.upload(xs) as dx, gpu_ctx.upload(ys) as dy:
+            z = gpu_ctx.overlaps(dx, dy)
+        err = float(np.abs(z - z_ref).max())
+        assert err < TOL, (case, n, chi_max, nx, ny, err)
+        worst = max(worst, err)
+    assert worst < TOL
