@@ -422,3 +422,19 @@ def test_randomised_shapes_against_oracle(gpu_ctx):
         assert err < TOL, (case, n, chi_max, nx, ny, err)
         worst = max(worst, err)
     assert worst < TOL
+
+
+def test_c_abi_example_runs(gpu_ctx, tmp_path):
+    """The plain-C program of examples/ (no Python between it and the library) reproduces a closed-form Gram."""
+    import os
+    import shutil
+    import subprocess
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "qk_example")
+    libdir = os.path.join(root, "qml-cutensornet_amd")
+    subprocess.run([shutil.which("gcc") or "gcc", "-O2", "-I", os.path.join(root, "include"), os.path.join(root, "examples", "c_abi_example.c"),
+                    "-o", exe, "-L", libdir, "-lqkgram", f"-Wl,-rpath,{libdir}", "-lm"], check=True)
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "max |K - closed form|" in r.stdout

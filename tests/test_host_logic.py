@@ -314,3 +314,22 @@ def test_driver_names_and_argument_errors():
         driver.main(["CPU", "8", "1", "1.0", "1", "10", "10", "5", "none.csv"])
     x, src = driver.load_training_features("definitely_missing.csv", 10, 10, 5, 8)
     assert src == "synthetic" and x.shape == (16, 8) and x.min() == 0.0 and abs(x.max() - 2.0) < 1e-12
+
+
+def test_c_abi_example_compiles_and_fails_loudly_without_gpu(built, tmp_path):
+    """examples/c_abi_example.c: plain C against include/qkgram.h and libqkgram.so (no Python in the loop)."""
+    import shutil
+    import subprocess
+
+    import torch
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "qk_example")
+    libdir = os.path.join(root, "qml-cutensornet_amd")
+    subprocess.run([shutil.which("gcc") or "gcc", "-O2", "-I", os.path.join(root, "include"), os.path.join(root, "examples", "c_abi_example.c"),
+                    "-o", exe, "-L", libdir, "-lqkgram", f"-Wl,-rpath,{libdir}", "-lm"], check=True)
+    r = subprocess.run([exe], capture_output=True, text=True)
+    if torch.cuda.is_available():
+        assert r.returncode == 0, r.stdout + r.stderr
+    else:
+        assert r.returncode == 2 and "no CPU fallback" in r.stderr
