@@ -133,7 +133,11 @@ int qk_plan_stats(const qk_plan* plan, qk_stats* out); /* algorithmic flops/byte
  *     values_dev[p] = |z_p|^2                 (G:380-383, J:106)
  *     z_dev[2p], z_dev[2p+1] = re, im of z_p  (optional, may be NULL)
  * One persistent launch; returns after enqueueing (asynchronous).
- * yset = NULL means Y is X.                                                    */
+ * yset = NULL means Y is X.
+ * The sweep kernel is chosen from the two sets' largest padded bond: 16 -> one pair per wavefront, entirely in
+ * registers (fp64); <= 32 -> X and T resident in LDS, site tensors streamed; otherwise the general ring kernel
+ * (X / T in an L2-resident scratch).  All three compute the same chain of complex GEMMs on the matrix cores and
+ * agree to rounding (tests/test_gpu_parity.py); QK_WAVE=0 / QK_SMALL=0 in the environment force the general one.  */
 int qk_gram_values(qk_ctx* ctx, const qk_mps_set* xset, const qk_mps_set* yset, const qk_plan* plan,
                    double* values_dev, double* z_dev);
 
