@@ -438,3 +438,23 @@ def test_c_abi_example_runs(gpu_ctx, tmp_path):
     r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "max |K - closed form|" in r.stdout
+
+
+def test_large_bonds(gpu_ctx):
+    """Bonds up to 300 (padded 304: five 64-wide passes per dimension, K tails): three states against the oracle."""
+    import qml_cutensornet_amd as Q
+    from oracle import restatement as R
+
+    rng = np.random.default_rng(17)
+    n = 22
+    caps = (300, 257, 129)
+    xs = [Q.random_mps(n, [min(2 ** min(k, n - k), c) for k in range(n + 1)], rng) for c in caps]
+    z_ref = np.array([[R.mps_inner(x.tensors, y.tensors) for x in xs] for y in xs])
+    with gpu_ctx.upload(xs) as dx:
+        assert dx.info()["max_padded_bond"] == 304
+        z = gpu_ctx.overlaps(dx)
+        with dx.to_f32() as fx:
+            z32 = gpu_ctx.overlaps(fx)
+    assert np.abs(z - z_ref).max() < TOL
+    assert np.abs(np.diag(z) - 1).max() < 1e-12
+    assert np.abs(z32 - z_ref).max() < F32_TOL
