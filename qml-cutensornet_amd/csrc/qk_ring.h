@@ -236,8 +236,13 @@ __device__ __forceinline__ void zgemm_ring3(T* __restrict__ Cre, T* __restrict__
     for (int kt = 0; kt < nk; ++kt, ++s) {  // (ring)
       if (s + DEPTH < total) fetch();                    // K-tile s+DEPTH -> the slot read in step s-1
       const T* base = lds + c_slot;
+      // Waves run at raised priority everywhere EXCEPT inside the MFMA block: a wave that is issuing DMAs, waiting at the
+      // barrier or setting up a pass gets the issue slots ahead of the co-resident workgroup's MFMA stream and is back at
+      // its own MFMAs sooner (measured 524 vs 533 ms on cfg4; the opposite assignment costs 1 %).
+      __builtin_amdgcn_s_setprio(0);
       if (kt + 1 < nk || ks_last == KTL / 4) mma_ring3<CONJB, CNT, true, M3, KTL, PN, T>(c1, c2, c3, la, lb, base, KTL / 4);
       else mma_ring3<CONJB, CNT, false, M3, KTL, PN, T>(c1, c2, c3, la, lb, base, ks_last);
+      __builtin_amdgcn_s_setprio(2);
       if (s + 1 < total) {
         // K-tile s+1 must have landed; everything issued after it may stay in flight: the younger K-tiles and,
         // when it was issued before the previous step's epilogue (DEPTH >= 2), that epilogue's stores
