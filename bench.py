@@ -96,6 +96,16 @@ def build_or_load_states(name, n, reps, d, gamma, npts, seed, rank, world, worke
     return states, {"built_here": built, "build_wall_s": build_wall, "cpu_s_per_state": float(np.mean(secs))}
 
 
+def sweep_kernel_name(max_padded_bond, precision):
+    """The kernel qk_gram_values selects for a set (include/qkgram.h): by the largest padded bond and the precision."""
+    t = "double" if precision == "f64" else "float"
+    if max_padded_bond <= 16 and precision == "f64" and os.environ.get("QK_WAVE", "1") != "0":
+        return "qk_sweep_wave_kernel<0>"
+    if max_padded_bond <= 32 and os.environ.get("QK_SMALL", "1") != "0":
+        return f"qk_sweep_small_kernel<{t}>"
+    return f"qk_sweep_ring_kernel<{t}>"
+
+
 def cpu_baseline(states, pairs, total_unique, npts, seconds, gpu_vals, threads):
     """Time the oracle's C restatement on a bounded random sample of this Gram's pairs."""
     from oracle import c_oracle
@@ -290,7 +300,7 @@ def main():
             },
             "roofline": {
                 "bound": "mfma",  # fp64 matrix cores for f64, fp32 matrix cores for f32
-                "kernel": "qk_sweep_ring_kernel<double>" if args.precision == "f64" else "qk_sweep_ring_kernel<float>",
+                "kernel": sweep_kernel_name(info["max_padded_bond"], args.precision),
                 "achieved": achieved,
                 "peak": peak,
                 "unit": "TFLOP/s",
