@@ -116,6 +116,66 @@ def _kept(s: np.ndarray, discard_budget: float, zero: float) -> tuple[int, float
     return keep, float(w[:keep].sum()) / total
 
 
+_NATIVE = None  # ctypes handle of libqkbuilder.so, False once loading has failed
+
+
+def _native_builder():
+    """The native host builder (csrc/qk_builder.cpp), or None: it needs libqkbuilder.so (built by
+    ``__graft_entry__.build()``) and the OpenBLAS that scipy ships (for zgesdd / zgeqrf / zungqr / zgemm)."""
+    global _NATIVE
+    if _NATIVE is None:
+        import ctypes as C
+        import glob
+        import os
+
+        _NATIVE = False
+        try:
+            import scipy
+
+            here = os.path.dirname(os.path.abspath(__file__))
+            blas = sorted(glob.glob(os.path.join(os.path.dirname(scipy.__file__), "..", "scipy.libs", "libscipy_openblas*.so")))
+            lib = C.CDLL(os.path.join(here, "libqkbuilder.so"))
+            lib.qkb_last_error.restype = C.c_char_p
+            lib.qkb_init.argtypes = [C.c_char_p]
+            lib.qkb_simulate.argtypes = [C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_double,
+                                         C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int64), C.POINTER(C.c_double)]
+            lib.qkb_free.argtypes = [C.c_void_p]
+            if blas and lib.qkb_init(os.path.realpath(blas[0]).encode()) == 0:
+                _NATIVE = lib
+        except OSError:
+            _NATIVE = False
+    return _NATIVE or None
+
+
+def simulate_native(circuit: BoundCircuit, truncation_fidelity: float = 1.0 - 1e-16, value_of_zero: float = 1e-16) -> MPS:
+    """``simulate`` through the native builder: same algorithm and LAPACK routines, no interpreter in the gate loop."""
+    import ctypes as C
+
+    lib = _native_builder()
+    if lib is None:
+        raise RuntimeError("native MPS builder unavailable (libqkbuilder.so or scipy's OpenBLAS not found)")
+    n = circuit.n_qubits
+    op = np.ascontiguousarray(circuit.op, dtype=np.int8)
+    q0 = np.ascontiguousarray(circuit.q0, dtype=np.int32)
+    alpha = np.ascontiguousarray(circuit.alpha, dtype=np.float64)
+    dims = np.zeros(n + 1, dtype=np.int32)
+    block, count, fid = C.c_void_p(), C.c_int64(), C.c_double()
+    rc = lib.qkb_simulate(n, int(op.shape[0]), op.ctypes.data, q0.ctypes.data, alpha.ctypes.data, max(0.0, 1.0 - float(truncation_fidelity)),
+                          float(value_of_zero), dims.ctypes.data, C.byref(block), C.byref(count), C.byref(fid))
+    if rc != 0:
+        raise RuntimeError(f"native MPS builder failed: {lib.qkb_last_error().decode()}")
+    try:
+        flat = np.ctypeslib.as_array(C.cast(block, C.POINTER(C.c_double)), shape=(2 * count.value,)).view(np.complex128).copy()
+    finally:
+        lib.qkb_free(block)
+    tensors, pos = [], 0
+    for k in range(n):
+        sz = int(dims[k]) * 2 * int(dims[k + 1])
+        tensors.append(flat[pos : pos + sz].reshape(int(dims[k]), 2, int(dims[k + 1])))
+        pos += sz
+    return MPS(tensors, fid.value)
+
+
 def simulate(circuit: BoundCircuit, truncation_fidelity: float = 1.0 - 1e-16, value_of_zero: float = 1e-16) -> MPS:
     """MPS of circuit|0...0>, "MPSxGate" style: one SVD per two-qubit gate (ref :221).
 
@@ -127,7 +187,16 @@ def simulate(circuit: BoundCircuit, truncation_fidelity: float = 1.0 - 1e-16, va
     except ImportError:  # pragma: no cover - optional dependency
         return _simulate(circuit, truncation_fidelity, value_of_zero)
     with threadpool_limits(limits=1):
+        if _use_native():
+            return simulate_native(circuit, truncation_fidelity, value_of_zero)
         return _simulate(circuit, truncation_fidelity, value_of_zero)
+
+
+def _use_native() -> bool:
+    """QK_NATIVE_BUILDER=0 forces the numpy/scipy loop; otherwise the native builder is used when it loads."""
+    import os
+
+    return os.environ.get("QK_NATIVE_BUILDER", "1") != "0" and _native_builder() is not None
 
 
 def _simulate(circuit: BoundCircuit, truncation_fidelity: float, value_of_zero: float) -> MPS:

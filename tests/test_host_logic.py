@@ -333,3 +333,41 @@ def test_c_abi_example_compiles_and_fails_loudly_without_gpu(built, tmp_path):
         assert r.returncode == 0, r.stdout + r.stderr
     else:
         assert r.returncode == 2 and "no CPU fallback" in r.stderr
+
+
+@pytest.mark.parametrize("n,reps,gamma,d", [(8, 1, 1.0, 1), (12, 3, 0.8, 3), (24, 3, 1.0, 2)])
+def test_native_builder_matches_numpy_builder(built, n, reps, gamma, d):
+    """csrc/qk_builder.cpp (native host builder) against the numpy/scipy loop it mirrors: same bonds, same fidelity,
+    the same states (cross overlaps of modulus 1) -- and both against the oracle's own simulate."""
+    import qml_cutensornet_amd as Q
+    from oracle import restatement as R
+    from qml_cutensornet_amd import mps as M
+
+    assert M._native_builder() is not None, "libqkbuilder.so / scipy OpenBLAS not found"
+    X = R.synthetic_features(4, n, 7)
+    ans = Q.KernelStateAnsatz(n, reps, gamma, Q.entanglement_graph(n, d))
+    for x in X:
+        c = ans.circuit_for_data(x)
+        a = M._simulate(c, 1 - 1e-16, 1e-16)
+        b = M.simulate_native(c, 1 - 1e-16, 1e-16)
+        assert (a.bond_dims() == b.bond_dims()).all()
+        assert abs(a.fidelity - b.fidelity) < 1e-12
+        assert abs(abs(R.mps_inner(a.tensors, b.tensors)) - 1) < 1e-12
+    # truncation active: fewer bonds, same rule
+    c = ans.circuit_for_data(X[0])
+    a = M._simulate(c, 1 - 1e-6, 1e-16)
+    b = M.simulate_native(c, 1 - 1e-6, 1e-16)
+    assert (a.bond_dims() == b.bond_dims()).all() and abs(a.fidelity - b.fidelity) < 1e-12
+
+
+def test_simulate_falls_back_without_native(monkeypatch):
+    import qml_cutensornet_amd as Q
+    from qml_cutensornet_amd import mps as M
+
+    ans = Q.KernelStateAnsatz(6, 1, 1.0, Q.entanglement_graph(6, 1))
+    c = ans.circuit_for_data(np.linspace(0.1, 1.7, 6))
+    monkeypatch.setenv("QK_NATIVE_BUILDER", "0")
+    a = Q.simulate(c)
+    monkeypatch.setenv("QK_NATIVE_BUILDER", "1")
+    b = Q.simulate(c)
+    assert (a.bond_dims() == b.bond_dims()).all()
