@@ -5,12 +5,12 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 export QK_CACHE_DIR=${QK_CACHE_DIR:-/tmp/qkc}
 OUT=$R/gpurun_out/pmc_$TAG; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-python3 $R/bench.py --steps 1 --warmup 0 --cpu-seconds 0 > /dev/null 2> $OUT/prime.err || { tail -3 $OUT/prime.err; exit 1; }
+python3 $R/bench.py $QK_BENCH_ARGS --steps 1 --warmup 0 --cpu-seconds 0 > /dev/null 2> $OUT/prime.err || { tail -3 $OUT/prime.err; exit 1; }
 for vw in $1; do
   v=${vw%%:*}; w=${vw##*:}
   for ctr in FETCH_SIZE WRITE_SIZE "TCC_HIT_sum TCC_MISS_sum"; do
     name=$(echo $ctr | tr ' ' '_')
-    QK_VARIANT=$v QK_WGS_PER_CU=$w rocprofv3 --kernel-trace --pmc $ctr --output-format csv -d $OUT/${v}_${w}_$name -o pmc -- python3 $R/bench.py --steps 1 --warmup 0 --cpu-seconds 0 > /dev/null 2> $OUT/${v}_${w}_$name.err || echo "pass failed: $vw $ctr"
+    QK_VARIANT=$v QK_WGS_PER_CU=$w rocprofv3 --kernel-trace --pmc $ctr --output-format csv -d $OUT/${v}_${w}_$name -o pmc -- python3 $R/bench.py $QK_BENCH_ARGS --steps 1 --warmup 0 --cpu-seconds 0 > /dev/null 2> $OUT/${v}_${w}_$name.err || echo "pass failed: $vw $ctr"
   done
   python3 - <<PY
 import csv, glob, collections
