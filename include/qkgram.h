@@ -175,6 +175,27 @@ int qk_debug_mma_bench(qk_ctx* ctx, int which, int wgs_per_cu, int reps, double*
  * 0 if the 16x16x4 product of two known matrices matches the host result). */
 int qk_selftest_mfma(qk_ctx* ctx);
 
+/* ---- device MPS builder ------------------------------------------------------------
+ * Replaces simulate(libhandle, circ, SimulationAlgorithm.MPSxGate, config) (G:141-144, 221, 263) for the
+ * ansatz gate program: all data points share the gate structure (op, q0: n_ops entries; 0 = H, 1 = Rz,
+ * 2 = XXPhase on (q0, q0+1), 3 = SWAP on (q0, q0+1)) and differ in the half-turn angles alpha[n_states][n_ops].
+ * One persistent launch; per two-qubit gate a one-sided Jacobi SVD and the truncation rule of the host builder:
+ * drop the trailing singular values whose squared weight stays <= trunc_budget (= 1 - truncation_fidelity,
+ * G:141-144; criterion as KernelPkg.jl:68), values <= value_of_zero never count.  max_bond bounds every bond
+ * (QK_EINVAL if a state outgrows it).  The result stays on the device until downloaded: per state and site a
+ * complex128 tensor [chi_l][2][chi_r] row-major, sites back to back, state s at offsets[s] (complex elements).    */
+typedef struct qk_built qk_built;
+int qk_build_mps(qk_ctx* ctx, int32_t n_states, int32_t n_qubits, int32_t n_ops, const int8_t* op, const int32_t* q0,
+                 const double* alpha, double trunc_budget, double value_of_zero, int32_t max_bond, qk_built** out);
+/* dims[n_states][n_qubits+1], fidelity[n_states], offsets[n_states], total complex elements, kernel time; any may be NULL */
+int qk_built_info(const qk_built* built, int32_t* dims, double* fidelity, int64_t* offsets, int64_t* total_complex,
+                  double* kernel_ms);
+int qk_built_download(const qk_built* built, double* host /* 2 * total_complex doubles (re, im interleaved) */);
+int qk_built_destroy(qk_built* built);
+/* Diagnostic: the builder's Jacobi primitive on one host matrix a[p][q] (complex128 row-major, overwritten by A V);
+ * v_out[q][q], sig_out[q] = column norms of A V, ord_out[q] = columns by decreasing norm.                          */
+int qk_debug_jacobi(qk_ctx* ctx, int32_t p, int32_t q, double* a_inout, double* v_out, double* sig_out, int32_t* ord_out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,691 @@
+// qk_build.hip -- device MPS builder: the input producer of the Gram path on the GPU.
+// Replaces simulate(libhandle, circ, SimulationAlgorithm.MPSxGate, config) of the reference
+// (gpu_backend/kernel_state_ansatz.py:141-144, 221, 263; truncation criterion as KernelPkg.jl:68) for the ansatz gate
+// program (H, Rz, XXPhase, SWAP on adjacent qubits: qml-cutensornet_amd/ansatz.py).  Same algorithm as the host
+// builder (csrc/qk_builder.cpp, mps.py:_simulate) -- orthogonality centre carried along, one SVD per two-qubit gate,
+// fewest singular values whose weight keeps the fidelity -- restated for the device:
+//   * all data points share ONE gate structure and differ only in the angles, so the whole list is one persistent
+//     launch: a workgroup pulls a state index from a device counter and runs that state's complete gate program;
+//   * the only dense factorisation is a one-sided (Hestenes) Jacobi sweep over column pairs, 16 lanes per pair and
+//     32 pairs per step in round-robin order: it serves as the SVD of a gate's theta matrix and, with the same code, as
+//     the rank-revealing orthogonalisation of a centre move (M = (W/s)(s V^H) instead of QR);
+//   * site tensors live in a per-workgroup arena (fixed slots of 2*cap^2 complex), theta / V / temporaries in a
+//     per-workgroup workspace -- L2-resident at the bonds of the reference's workloads; finished states are packed
+//     into one heap (atomic bump) and described by dims / offsets / fidelity arrays.
+// Round-1 scope: correctness and a first measurement; the matrices stay in global memory (no LDS-resident path yet).
+#include "qk_host.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+
+namespace {
+typedef double2 cd;
+constexpr int BT = 512;       // threads per workgroup
+constexpr int GL = 16;        // lanes that share one column pair
+constexpr int NG = BT / GL;   // column pairs per step
+constexpr int MAX_SWEEPS = 40;
+enum { OP_H = 0, OP_RZ = 1, OP_XX = 2, OP_SWAP = 3 };  // ansatz.py
+enum { ERR_BOND = 1, ERR_HEAP = 2, ERR_SWEEPS = 4, ERR_GATE = 8 };
+
+__device__ __forceinline__ cd cmul(const cd a, const cd b) { return cd{a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x}; }
+__device__ __forceinline__ cd cfma(const cd a, const cd b, const cd c) { return cd{c.x + a.x * b.x - a.y * b.y, c.y + a.x * b.y + a.y * b.x}; }
+
+struct BuildArgs {
+  int n_states, n_qubits, n_ops, cap;
+  const int8_t* op;
+  const int32_t* q0;
+  const double* alpha;  // [n_states][n_ops] half-turns
+  double budget, zero;
+  cd* arena;  // per workgroup: n_qubits slots of 2 cap^2
+  cd* work;   // per workgroup: 3 buffers of 4 cap^2
+  cd* heap;
+  unsigned long long heap_cap;
+  unsigned long long* heap_top;
+  int32_t* dims_out;    // [n_states][n_qubits + 1]
+  double* fid_out;      // [n_states]
+  long long* offs_out;  // [n_states] complex elements into heap
+  unsigned long long* counter;
+  int* error;     // [0] error bits, [1..4] Jacobi statistics: factorisations, sweeps, most sweeps, unconverged
+  int jl_offset;  // doubles from the start of the dynamic LDS to the Jacobi working set
+  int jl_elems;   // complex elements it holds
+};
+
+// Shared scalars of a workgroup (one instance in LDS).
+struct WgShared {
+  int flag, keep, state, pad;
+  double frac, nrm;
+  unsigned long long off;
+};
+
+// One-sided Jacobi.  A is p x q, element (i, j) at A[i * rs + j * cs].  On return A <- A V with mutually orthogonal columns and V
+// (q x q, row-major) holds the accumulated unitary; sig[j] = |column j|, ord = column indices by decreasing sig.
+__device__ void jacobi_orth(cd* A, const long rs, const long cs, const int p, const int q, cd* V, const int ldv,
+                            double* sig, int* ord, WgShared* sh, int* error) {
+  const int tid = threadIdx.x, grp = tid / GL, gl = tid % GL;
+  for (int e = tid; e < q * q; e += BT) V[(e / q) * ldv + e % q] = cd{(e / q == e % q) ? 1.0 : 0.0, 0.0};
+  const double tol2 = 1e-30 * (double)max(p, 10);  // (eps sqrt(p))^2-ish: the rounding floor of a length-p inner product
+  for (int jc = grp; jc < q; jc += NG) {  // squared Frobenius norm (sets the absolute floor of the rotation test)
+    double al = 0;
+    for (int i = gl; i < p; i += GL) {
+      const cd x = A[i * rs + jc * cs];
+      al += x.x * x.x + x.y * x.y;
+    }
+#pragma unroll
+    for (int m = GL / 2; m > 0; m >>= 1) al += __shfl_xor(al, m, GL);
+    sig[jc] = al;
+  }
+  __syncthreads();
+  double frob = 0;
+  for (int jc = 0; jc < q; ++jc) frob += sig[jc];
+  __syncthreads();
+  if (q >= 2) {
+    const int qe = q + (q & 1), half = qe / 2, nr = qe - 1;
+    int sweep = 0;
+    for (; sweep < MAX_SWEEPS; ++sweep) {
+      if (tid == 0) sh->flag = 0;
+      __syncthreads();
+      for (int r = 0; r < nr; ++r) {
+        for (int k = grp; k < half; k += NG) {
+          int c1 = (k == 0) ? nr : (r + k) % nr;
+          int c2 = (k == 0) ? r : (r - k + nr) % nr;
+          if (c1 < q && c2 < q) {
+            if (c1 > c2) {
+              const int t_ = c1;
+              c1 = c2, c2 = t_;
+            }
+            cd* a1 = A + c1 * cs;
+            cd* a2 = A + c2 * cs;
+            double al = 0, be = 0, gr = 0, gi = 0;
+            for (int i = gl; i < p; i += GL) {
+              const cd x = a1[i * rs], y = a2[i * rs];
+              al += x.x * x.x + x.y * x.y;
+              be += y.x * y.x + y.y * y.y;
+              gr += x.x * y.x + x.y * y.y;  // conj(x) * y
+              gi += x.x * y.y - x.y * y.x;
+            }
+#pragma unroll
+            for (int m = GL / 2; m > 0; m >>= 1) {
+              al += __shfl_xor(al, m, GL);
+              be += __shfl_xor(be, m, GL);
+              gr += __shfl_xor(gr, m, GL);
+              gi += __shfl_xor(gi, m, GL);
+            }
+            const double g2 = gr * gr + gi * gi;
+            // rotate when |<a1, a2>| > tol |a1| max(|a2|, 0.03 |A|_F), a1 the longer column: relative orthogonality for
+            // the columns that carry weight, the absolute accuracy of a LAPACK SVD (eps |A|) for the short ones -- whose
+            // directions are rounding noise of the products that made A and would never settle under the relative test
+            if (g2 > tol2 * fmax(al, be) * fmax(fmin(al, be), 1e-3 * frob)) {
+              const double ga = sqrt(g2);
+              const double zeta = (be - al) / (2.0 * ga);
+              const double t = copysign(1.0, zeta) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+              const double c = 1.0 / sqrt(1.0 + t * t), s = c * t;
+              const double phr = gr / ga, phi = gi / ga;  // e^{i phi}
+              const cd s1 = cd{-s * phr, s * phi};        // -s conj(ph)
+              const cd s2 = cd{s * phr, s * phi};         //  s ph
+              for (int i = gl; i < p; i += GL) {
+                const cd x = a1[i * rs], y = a2[i * rs];
+                a1[i * rs] = cfma(s1, y, cd{c * x.x, c * x.y});
+                a2[i * rs] = cfma(s2, x, cd{c * y.x, c * y.y});
+              }
+              for (int i = gl; i < q; i += GL) {
+                const cd x = V[i * ldv + c1], y = V[i * ldv + c2];
+                V[i * ldv + c1] = cfma(s1, y, cd{c * x.x, c * x.y});
+                V[i * ldv + c2] = cfma(s2, x, cd{c * y.x, c * y.y});
+              }
+              sh->flag = 1;
+            }
+          }
+        }
+        __syncthreads();
+      }
+      const int f = sh->flag;
+      __syncthreads();
+      if (!f) break;
+    }
+    if (tid == 0) {
+      if (sweep == MAX_SWEEPS) atomicOr(error, ERR_SWEEPS), atomicAdd(error + 4, 1);
+      atomicAdd(error + 1, 1);              // statistics: factorisations, sweeps, most sweeps of one factorisation
+      atomicAdd(error + 2, min(sweep + 1, MAX_SWEEPS));
+      atomicMax(error + 3, min(sweep + 1, MAX_SWEEPS));
+    }
+  }
+  for (int jc = grp; jc < q; jc += NG) {
+    double al = 0;
+    for (int i = gl; i < p; i += GL) {
+      const cd x = A[i * rs + jc * cs];
+      al += x.x * x.x + x.y * x.y;
+    }
+#pragma unroll
+    for (int m = GL / 2; m > 0; m >>= 1) al += __shfl_xor(al, m, GL);
+    sig[jc] = sqrt(al);
+  }
+  __syncthreads();
+  for (int jc = tid; jc < q; jc += BT) {
+    const double v = sig[jc];
+    int rank = 0;
+    for (int i = 0; i < q; ++i) {
+      const double u = sig[i];
+      rank += (u > v) || (u == v && i < jc);
+    }
+    ord[rank] = jc;
+  }
+  __syncthreads();
+}
+
+// The same factorisation with the working set in LDS when it fits (A and V side by side, odd leading dimension so
+// that the 16 lanes of a pair hit 16 different banks): a step is then a few hundred cycles instead of a store-drain +
+// L2 round trip.  Results are copied back to the global A (same strides) and to V (row-major, ld q).
+__device__ void jacobi_auto(cd* A, const long rs, const long cs, const int p, const int q, cd* V, double* sig, int* ord, WgShared* sh,
+                            int* error, cd* lds, const int lds_elems) {
+  const int ld = q | 1;
+  if ((long)(p + q) * ld <= lds_elems) {
+    cd* LA = lds;
+    cd* LV = lds + (long)p * ld;
+    for (int e = threadIdx.x; e < p * q; e += BT) {
+      const int i = e / q, jc = e - i * q;
+      LA[i * ld + jc] = A[i * rs + jc * cs];
+    }
+    __syncthreads();
+    jacobi_orth(LA, ld, 1, p, q, LV, ld, sig, ord, sh, error);
+    for (int e = threadIdx.x; e < p * q; e += BT) {
+      const int i = e / q, jc = e - i * q;
+      A[i * rs + jc * cs] = LA[i * ld + jc];
+    }
+    for (int e = threadIdx.x; e < q * q; e += BT) {
+      const int i = e / q, jc = e - i * q;
+      V[e] = LV[i * ld + jc];
+    }
+    __syncthreads();
+  } else {
+    jacobi_orth(A, rs, cs, p, q, V, q, sig, ord, sh, error);
+  }
+}
+
+// C[M x N] (row-major, ld N) = sum_k A(i, k) B(k, j); A(i, k) at A[i * ars + k * acs], B(k, j) at B[k * brs + j * bcs]
+__device__ void wg_gemm(cd* __restrict__ C, const int M, const int N, const int K, const cd* __restrict__ A, const long ars, const long acs,
+                        const cd* __restrict__ B, const long brs, const long bcs) {
+  for (int e = threadIdx.x; e < M * N; e += BT) {
+    const int i = e / N, jn = e - i * N;
+    cd acc = cd{0.0, 0.0};
+    const cd* pa = A + i * ars;
+    const cd* pb = B + jn * bcs;
+    for (int k = 0; k < K; ++k) acc = cfma(pa[k * acs], pb[k * brs], acc);
+    C[e] = acc;
+  }
+  __syncthreads();
+}
+
+__device__ void wg_copy(cd* __restrict__ dst, const cd* __restrict__ src, const long n) {
+  for (long e = threadIdx.x; e < n; e += BT) dst[e] = src[e];
+  __syncthreads();
+}
+
+// thread 0: how many leading (sorted) singular values survive (qk_builder.cpp: kept(), mps.py:_kept); results in sh
+__device__ void wg_kept(const double* sig, const int* ord, const int n, const double budget, const double zero, WgShared* sh) {
+  if (threadIdx.x == 0) {
+    double total = 0;
+    for (int i = 0; i < n; ++i) total += sig[i] * sig[i];
+    int keep = 0;
+    for (int i = 0; i < n; ++i) keep += (sig[i] > zero);
+    keep = max(keep, 1);
+    double tail = 0;
+    int drop = 0;
+    for (int i = keep - 1; i >= 0; --i) {
+      const double s = sig[ord[i]];
+      tail += s * s;
+      if (tail <= budget * total) ++drop;
+      else break;
+    }
+    keep = max(keep - drop, 1);
+    double w = 0;
+    for (int i = 0; i < keep; ++i) {
+      const double s = sig[ord[i]];
+      w += s * s;
+    }
+    sh->keep = keep;
+    sh->frac = (total > 0) ? w / total : 1.0;
+    sh->nrm = sqrt(w);
+  }
+  __syncthreads();
+}
+
+__global__ __launch_bounds__(BT) void qk_build_kernel(const BuildArgs g) {
+  extern __shared__ double sh_raw[];
+  const int n = g.n_qubits, cap = g.cap, tid = threadIdx.x;
+  double* sig = sh_raw;                                   // [2 cap]
+  int* ord = reinterpret_cast<int*>(sig + 2 * cap);      // [2 cap]
+  int* dims = ord + 2 * cap;                              // [n + 1]
+  cd* const jl = reinterpret_cast<cd*>(sh_raw + g.jl_offset);  // LDS working set of the Jacobi factorisations
+  __shared__ WgShared sh;
+  const long slot = 2L * cap * cap, wslot = 4L * cap * cap;
+  cd* const sites = g.arena + (long)blockIdx.x * n * slot;
+  cd* const TH = g.work + (long)blockIdx.x * 3 * wslot;
+  cd* const VV = TH + wslot;
+  cd* const TMP = VV + wslot;
+  const double sqrt_half = 0.7071067811865476;
+  for (;;) {
+    if (tid == 0) sh.state = (int)atomicAdd(g.counter, 1ull);
+    __syncthreads();
+    const int st = sh.state;
+    __syncthreads();
+    if (st >= g.n_states) break;
+    for (int k = tid; k <= n; k += BT) dims[k] = 1;
+    for (int k = tid; k < n; k += BT) {
+      sites[k * slot] = cd{1.0, 0.0};
+      sites[k * slot + 1] = cd{0.0, 0.0};
+    }
+    __syncthreads();
+    const double* alpha = g.alpha + (long)st * g.n_ops;
+    double fidelity = 1.0;
+    int centre = 0;
+    for (int i = 0; i < g.n_ops; ++i) {
+      const int o = g.op[i], q = g.q0[i];
+      if (q < 0 || q >= n || (o >= OP_XX && q + 1 >= n) || o < 0 || o > OP_SWAP) {
+        if (tid == 0) atomicOr(g.error, ERR_GATE);
+        continue;
+      }
+      if (o == OP_H || o == OP_RZ) {
+        cd* t = sites + q * slot;
+        const int l = dims[q], r = dims[q + 1];
+        const double th = 0.5 * M_PI * alpha[i];
+        const cd ph = cd{cos(th), sin(th)};
+        for (int e = tid; e < l * r; e += BT) {
+          const int a = e / r, c = e - a * r;
+          const cd t0 = t[(a * 2) * r + c], t1 = t[(a * 2 + 1) * r + c];
+          if (o == OP_H) {
+            t[(a * 2) * r + c] = cd{(t0.x + t1.x) * sqrt_half, (t0.y + t1.y) * sqrt_half};
+            t[(a * 2 + 1) * r + c] = cd{(t0.x - t1.x) * sqrt_half, (t0.y - t1.y) * sqrt_half};
+          } else {
+            t[(a * 2) * r + c] = cmul(t0, cd{ph.x, -ph.y});
+            t[(a * 2 + 1) * r + c] = cmul(t1, ph);
+          }
+        }
+        __syncthreads();
+        continue;
+      }
+      // ---- two-qubit gate on (q, q+1): bring the orthogonality centre onto the pair
+      while (centre < q) {  // t = (W/s), next <- (s V^H) next
+        cd* t = sites + centre * slot;
+        cd* u = sites + (centre + 1) * slot;
+        const int l = dims[centre], r = dims[centre + 1], r2 = dims[centre + 2];
+        const int m = 2 * l;
+        jacobi_auto(t, r, 1, m, r, VV, sig, ord, &sh, g.error, jl, g.jl_elems);
+        if (tid == 0) {
+          int k = 0;
+          const double smax = sig[ord[0]];
+          for (int jj = 0; jj < r; ++jj) k += (sig[ord[jj]] > 1e-15 * smax);
+          sh.keep = max(k, 1);
+        }
+        __syncthreads();
+        const int k = sh.keep;
+        for (int e = tid; e < m * k; e += BT) {  // Q[row][jj] = W[row][ord jj] / s
+          const int row = e / k, jj = e - row * k;
+          const int c = ord[jj];
+          const double s = sig[c];
+          const cd w = t[row * r + c];
+          TMP[e] = (s > 0) ? cd{w.x / s, w.y / s} : cd{0.0, 0.0};
+        }
+        // R[jj][c] = s_jj conj(V[c][ord jj]); u'[jj][x] = sum_c R[jj][c] u[c][x]
+        for (int e = tid; e < k * 2 * r2; e += BT) {
+          const int jj = e / (2 * r2), x = e - jj * (2 * r2);
+          const int cj = ord[jj];
+          cd acc = cd{0.0, 0.0};
+          for (int c = 0; c < r; ++c) {
+            const cd v = VV[c * r + cj];
+            acc = cfma(cd{v.x, -v.y}, u[c * (2 * r2) + x], acc);
+          }
+          const double s = sig[cj];
+          TH[e] = cd{acc.x * s, acc.y * s};
+        }
+        __syncthreads();
+        wg_copy(t, TMP, (long)m * k);
+        wg_copy(u, TH, (long)k * 2 * r2);
+        if (tid == 0) dims[centre + 1] = k;
+        __syncthreads();
+        ++centre;
+      }
+      while (centre > q + 1) {  // t^T = (W/s)(s V^H): t <- (W/s)^T, previous <- previous (s V^H)^T
+        cd* t = sites + centre * slot;
+        cd* d = sites + (centre - 1) * slot;
+        const int l = dims[centre], r = dims[centre + 1], l0 = dims[centre - 1];
+        const int w = 2 * r;
+        // A(i = (p, c), j = a) = t[a][i]: rs = 1, cs = w
+        jacobi_auto(t, 1, w, w, l, VV, sig, ord, &sh, g.error, jl, g.jl_elems);
+        if (tid == 0) {
+          int k = 0;
+          const double smax = sig[ord[0]];
+          for (int jj = 0; jj < l; ++jj) k += (sig[ord[jj]] > 1e-15 * smax);
+          sh.keep = max(k, 1);
+        }
+        __syncthreads();
+        const int k = sh.keep;
+        for (int e = tid; e < k * w; e += BT) {  // t'[jj][i] = W(i, ord jj) / s = t[ord jj][i] / s
+          const int jj = e / w, ii = e - jj * w;
+          const int c = ord[jj];
+          const double s = sig[c];
+          const cd x = t[c * w + ii];
+          TMP[e] = (s > 0) ? cd{x.x / s, x.y / s} : cd{0.0, 0.0};
+        }
+        // t^T = Q R with R[jj][a] = s_jj conj(V[a][ord jj]);  d'[i][jj] = sum_a d[i][a] R[jj][a]
+        for (int e = tid; e < 2 * l0 * k; e += BT) {
+          const int row = e / k, jj = e - row * k;
+          const int cj = ord[jj];
+          cd acc = cd{0.0, 0.0};
+          for (int a = 0; a < l; ++a) {
+            const cd v = VV[a * l + cj];
+            acc = cfma(cd{v.x, -v.y}, d[row * l + a], acc);
+          }
+          const double s = sig[cj];
+          TH[e] = cd{acc.x * s, acc.y * s};
+        }
+        __syncthreads();
+        wg_copy(t, TMP, (long)k * w);
+        wg_copy(d, TH, (long)2 * l0 * k);
+        if (tid == 0) dims[centre] = k;
+        __syncthreads();
+        --centre;
+      }
+      cd* a0 = sites + q * slot;
+      cd* a1 = sites + (q + 1) * slot;
+      const int l = dims[q], mid = dims[q + 1], r = dims[q + 2];
+      const int m = 2 * l, nn = 2 * r;
+      wg_gemm(TH, m, nn, mid, a0, mid, 1, a1, nn, 1);  // theta[(a,p)][(p',c)]
+      {
+        const double th = 0.5 * M_PI * alpha[i];
+        const double cs = cos(th), sn = sin(th);
+        for (int e = tid; e < l * r; e += BT) {
+          const int a = e / r, c = e - a * r;
+          cd* p00 = TH + (long)(a * 2) * nn + c;
+          cd* p01 = p00 + r;
+          cd* p10 = TH + (long)(a * 2 + 1) * nn + c;
+          cd* p11 = p10 + r;
+          const cd t00 = *p00, t01 = *p01, t10 = *p10, t11 = *p11;
+          if (o == OP_SWAP) {
+            *p01 = t10;
+            *p10 = t01;
+          } else {  // XXPhase: cos(th) 1 - i sin(th) X(x)X ;  -i sn * (x + i y) = sn y - i sn x
+            *p00 = cd{cs * t00.x + sn * t11.y, cs * t00.y - sn * t11.x};
+            *p01 = cd{cs * t01.x + sn * t10.y, cs * t01.y - sn * t10.x};
+            *p10 = cd{cs * t10.x + sn * t01.y, cs * t10.y - sn * t01.x};
+            *p11 = cd{cs * t11.x + sn * t00.y, cs * t11.y - sn * t00.x};
+          }
+        }
+        __syncthreads();
+      }
+      // ---- SVD of theta[m x nn] by one-sided Jacobi on its smaller side
+      const bool cols = (nn <= m);
+      const int qd = cols ? nn : m;
+      if (cols) jacobi_auto(TH, nn, 1, m, nn, VV, sig, ord, &sh, g.error, jl, g.jl_elems);
+      else jacobi_auto(TH, 1, nn, nn, m, VV, sig, ord, &sh, g.error, jl, g.jl_elems);
+      wg_kept(sig, ord, qd, g.budget, g.zero, &sh);
+      int keep = sh.keep;
+      fidelity *= sh.frac;
+      const double nrm = sh.nrm;
+      if (keep > cap) {
+        if (tid == 0) atomicOr(g.error, ERR_BOND);
+        keep = cap;
+      }
+      int nxt = q;
+      for (int j2 = i + 1; j2 < g.n_ops; ++j2)
+        if (g.op[j2] >= OP_XX) {
+          nxt = g.q0[j2];
+          break;
+        }
+      const bool centre_right = (nxt >= q + 1) || (nxt == q);
+      // theta = U S Vh.  cols: U = W/s, Vh = V^H.  rows (theta^T = W V^H): U = conj(V), Vh[j][c] = W(c, j)/s = TH[j][c]/s.
+      for (int e = tid; e < m * keep; e += BT) {
+        const int row = e / keep, jj = e - row * keep;
+        const int c = ord[jj];
+        const double s = sig[c];
+        cd v;
+        if (cols) {
+          const cd w = TH[(long)row * nn + c];
+          v = (s > 0) ? cd{w.x / s, w.y / s} : cd{0.0, 0.0};
+        } else {
+          const cd w = VV[row * m + c];
+          v = cd{w.x, -w.y};
+        }
+        const double f = centre_right ? 1.0 : s / nrm;
+        a0[e] = cd{v.x * f, v.y * f};
+      }
+      for (int e = tid; e < keep * nn; e += BT) {
+        const int jj = e / nn, col = e - jj * nn;
+        const int c = ord[jj];
+        const double s = sig[c];
+        cd v;
+        if (cols) {
+          const cd w = VV[col * nn + c];
+          v = cd{w.x, -w.y};
+        } else {
+          const cd w = TH[(long)c * nn + col];
+          v = (s > 0) ? cd{w.x / s, w.y / s} : cd{0.0, 0.0};
+        }
+        const double f = centre_right ? s / nrm : 1.0;
+        a1[e] = cd{v.x * f, v.y * f};
+      }
+      if (tid == 0) dims[q + 1] = keep;
+      __syncthreads();
+      centre = centre_right ? q + 1 : q;
+    }
+    // ---- pack the finished state into the heap
+    if (tid == 0) {
+      unsigned long long total = 0;
+      for (int k = 0; k < n; ++k) total += 2ull * dims[k] * dims[k + 1];
+      const unsigned long long off = atomicAdd(g.heap_top, total);
+      sh.off = off;
+      sh.flag = (off + total <= g.heap_cap);
+      if (!sh.flag) atomicOr(g.error, ERR_HEAP);
+      g.offs_out[st] = (long long)off;
+      g.fid_out[st] = fidelity;
+    }
+    __syncthreads();
+    for (int k = tid; k <= n; k += BT) g.dims_out[(long)st * (n + 1) + k] = dims[k];
+    if (sh.flag) {
+      unsigned long long pos = sh.off;
+      for (int k = 0; k < n; ++k) {
+        const long cnt = 2L * dims[k] * dims[k + 1];
+        const cd* src = sites + k * slot;
+        for (long e = tid; e < cnt; e += BT) g.heap[pos + e] = src[e];
+        pos += cnt;
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// ---- debug: one Jacobi factorisation of a host matrix (tests the primitive on its own)
+__global__ __launch_bounds__(BT) void qk_jacobi_kernel(cd* A, int p, int q, cd* V, double* sig_out, int* ord_out, int* error) {
+  extern __shared__ double sh_raw[];
+  double* sig = sh_raw;
+  int* ord = reinterpret_cast<int*>(sig + q);
+  __shared__ WgShared sh;
+  jacobi_orth(A, q, 1, p, q, V, q, sig, ord, &sh, error);
+  for (int e = threadIdx.x; e < q; e += BT) {
+    sig_out[e] = sig[e];
+    ord_out[e] = ord[e];
+  }
+}
+}  // namespace
+
+struct qk_built {
+  qk_ctx* ctx = nullptr;
+  int n_states = 0, n_qubits = 0;
+  cd* heap = nullptr;
+  std::vector<int32_t> dims;
+  std::vector<double> fidelity;
+  std::vector<int64_t> offsets;
+  int64_t total = 0;
+  double kernel_ms = 0;
+};
+
+extern "C" int qk_build_mps(qk_ctx* c, int32_t n_states, int32_t n_qubits, int32_t n_ops, const int8_t* op, const int32_t* q0,
+                            const double* alpha, double trunc_budget, double value_of_zero, int32_t max_bond, qk_built** out) {
+  if (!c || !op || !q0 || !alpha || !out) return qk_fail(QK_EINVAL, "qk_build_mps: null argument");
+  if (n_states <= 0 || n_qubits <= 0 || n_ops < 0) return qk_fail(QK_EINVAL, "qk_build_mps: empty problem (%d states, %d qubits, %d gates)", n_states, n_qubits, n_ops);
+  if (max_bond < 2 || max_bond > 1024) return qk_fail(QK_EINVAL, "qk_build_mps: max_bond %d outside 2..1024", max_bond);
+  *out = nullptr;
+  HIP_TRY(hipSetDevice(c->device));
+  const int cap = max_bond;
+  size_t lds_meta = (size_t)2 * cap * sizeof(double) + (size_t)2 * cap * sizeof(int) + (size_t)(n_qubits + 1) * sizeof(int);
+  lds_meta = (lds_meta + 15) / 16 * 16;
+  if (lds_meta > 24 * 1024) return qk_fail(QK_EINVAL, "qk_build_mps: %d qubits at max_bond %d need %zu bytes of LDS", n_qubits, cap, lds_meta);
+  size_t lds_total = 156 * 1024;  // one workgroup per CU: the rest of the 160 KiB is the Jacobi working set
+  if (const char* v = std::getenv("QK_BUILD_LDS_KB")) lds_total = (size_t)std::max(32, std::min(156, std::atoi(v))) * 1024;
+  const int jl_elems = (int)((lds_total - lds_meta) / sizeof(cd));
+  const size_t lds = lds_total;
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(qk_build_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  const int wgs_per_cu = (lds_total <= 76 * 1024) ? 2 : 1;
+  size_t free_b = 0, total_b = 0;
+  HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+  const size_t per_wg = ((size_t)n_qubits * 2 * cap * cap + (size_t)3 * 4 * cap * cap) * sizeof(cd);
+  long long grid = std::min<long long>(n_states, (long long)wgs_per_cu * c->num_cus);
+  grid = std::min<long long>(grid, (long long)(0.35 * (double)free_b / (double)per_wg));
+  if (grid < 1) return qk_fail(QK_EDEVICE, "qk_build_mps: not enough device memory for one workgroup's arena (%zu bytes)", per_wg);
+  // heap: every finished state, packed; bounded by the arena size of all states and by the free memory
+  const double heap_want = (double)n_states * (double)n_qubits * 2.0 * cap * cap;
+  const size_t heap_cap = (size_t)std::min(heap_want, 0.45 * (double)free_b / (double)sizeof(cd));
+  cd *arena = nullptr, *work = nullptr, *heap = nullptr;
+  int8_t* d_op = nullptr;
+  int32_t* d_q0 = nullptr;
+  double *d_alpha = nullptr, *d_fid = nullptr;
+  int32_t* d_dims = nullptr;
+  long long* d_offs = nullptr;
+  unsigned long long* d_ctr = nullptr;  // [0] state counter, [1] heap top
+  int* d_err = nullptr;
+  auto release = [&]() {
+    (void)hipFree(arena), (void)hipFree(work), (void)hipFree(d_op), (void)hipFree(d_q0), (void)hipFree(d_alpha), (void)hipFree(d_fid);
+    (void)hipFree(d_dims), (void)hipFree(d_offs), (void)hipFree(d_ctr), (void)hipFree(d_err);
+  };
+#define BUILD_TRY(expr)                                                                                   \
+  do {                                                                                                    \
+    hipError_t e_ = (expr);                                                                               \
+    if (e_ != hipSuccess) {                                                                               \
+      release();                                                                                          \
+      (void)hipFree(heap);                                                                                \
+      return qk_fail(QK_EDEVICE, "qk_build_mps: %s failed: %s", #expr, hipGetErrorString(e_));            \
+    }                                                                                                     \
+  } while (0)
+  BUILD_TRY(hipMalloc(&arena, (size_t)grid * n_qubits * 2 * cap * cap * sizeof(cd)));
+  BUILD_TRY(hipMalloc(&work, (size_t)grid * 3 * 4 * cap * cap * sizeof(cd)));
+  BUILD_TRY(hipMalloc(&heap, heap_cap * sizeof(cd)));
+  BUILD_TRY(hipMalloc(&d_op, std::max(1, n_ops)));
+  BUILD_TRY(hipMalloc(&d_q0, (size_t)std::max(1, n_ops) * sizeof(int32_t)));
+  BUILD_TRY(hipMalloc(&d_alpha, (size_t)n_states * std::max(1, n_ops) * sizeof(double)));
+  BUILD_TRY(hipMalloc(&d_fid, (size_t)n_states * sizeof(double)));
+  BUILD_TRY(hipMalloc(&d_dims, (size_t)n_states * (n_qubits + 1) * sizeof(int32_t)));
+  BUILD_TRY(hipMalloc(&d_offs, (size_t)n_states * sizeof(long long)));
+  BUILD_TRY(hipMalloc(&d_ctr, 2 * sizeof(unsigned long long)));
+  BUILD_TRY(hipMalloc(&d_err, 8 * sizeof(int)));
+  if (n_ops > 0) {
+    BUILD_TRY(hipMemcpyAsync(d_op, op, n_ops, hipMemcpyHostToDevice, c->stream));
+    BUILD_TRY(hipMemcpyAsync(d_q0, q0, (size_t)n_ops * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+    BUILD_TRY(hipMemcpyAsync(d_alpha, alpha, (size_t)n_states * n_ops * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  }
+  BUILD_TRY(hipMemsetAsync(d_ctr, 0, 2 * sizeof(unsigned long long), c->stream));
+  BUILD_TRY(hipMemsetAsync(d_err, 0, 8 * sizeof(int), c->stream));
+  BuildArgs a;
+  a.n_states = n_states, a.n_qubits = n_qubits, a.n_ops = n_ops, a.cap = cap;
+  a.op = d_op, a.q0 = d_q0, a.alpha = d_alpha;
+  a.budget = trunc_budget, a.zero = value_of_zero;
+  a.arena = arena, a.work = work, a.heap = heap, a.heap_cap = heap_cap, a.heap_top = d_ctr + 1;
+  a.dims_out = d_dims, a.fid_out = d_fid, a.offs_out = d_offs, a.counter = d_ctr, a.error = d_err;
+  a.jl_offset = (int)(lds_meta / sizeof(double)), a.jl_elems = jl_elems;
+  BUILD_TRY(hipEventRecord(c->ev0, c->stream));
+  qk_build_kernel<<<dim3((unsigned)grid), dim3(BT), lds, c->stream>>>(a);
+  BUILD_TRY(hipGetLastError());
+  BUILD_TRY(hipEventRecord(c->ev1, c->stream));
+  qk_built* b = new qk_built;
+  b->ctx = c, b->n_states = n_states, b->n_qubits = n_qubits;
+  b->dims.resize((size_t)n_states * (n_qubits + 1));
+  b->fidelity.resize(n_states);
+  b->offsets.resize(n_states);
+  std::vector<long long> offs(n_states);
+  int errv[8] = {0};
+  unsigned long long ctr[2] = {0, 0};
+  hipError_t e = hipStreamSynchronize(c->stream);
+  if (e == hipSuccess) e = hipMemcpy(b->dims.data(), d_dims, b->dims.size() * sizeof(int32_t), hipMemcpyDeviceToHost);
+  if (e == hipSuccess) e = hipMemcpy(b->fidelity.data(), d_fid, (size_t)n_states * sizeof(double), hipMemcpyDeviceToHost);
+  if (e == hipSuccess) e = hipMemcpy(offs.data(), d_offs, (size_t)n_states * sizeof(long long), hipMemcpyDeviceToHost);
+  if (e == hipSuccess) e = hipMemcpy(errv, d_err, sizeof(errv), hipMemcpyDeviceToHost);
+  if (e == hipSuccess) e = hipMemcpy(ctr, d_ctr, sizeof(ctr), hipMemcpyDeviceToHost);
+  float ms = 0;
+  if (e == hipSuccess) e = hipEventElapsedTime(&ms, c->ev0, c->ev1);
+  release();
+  if (e != hipSuccess) {
+    (void)hipFree(heap);
+    delete b;
+    return qk_fail(QK_EDEVICE, "qk_build_mps: %s", hipGetErrorString(e));
+  }
+  const int err = errv[0];
+  if (std::getenv("QK_BUILD_DEBUG"))
+    std::fprintf(stderr, "[qk_build_mps] %d states, grid %lld, %.1f ms; Jacobi: %d factorisations, %.2f sweeps on average, %d at most, %d unconverged; error bits %d\n",
+                 n_states, grid, ms, errv[1], errv[1] ? (double)errv[2] / errv[1] : 0.0, errv[3], errv[4], err);
+  if (err) {
+    (void)hipFree(heap);
+    delete b;
+    if (err & ERR_GATE) return qk_fail(QK_EINVAL, "qk_build_mps: gate on a qubit outside the register");
+    if (err & ERR_BOND) return qk_fail(QK_EINVAL, "qk_build_mps: a bond grew beyond max_bond = %d", cap);
+    if (err & ERR_HEAP) return qk_fail(QK_EDEVICE, "qk_build_mps: the packed states need %llu complex numbers, the heap holds %zu", ctr[1], heap_cap);
+    return qk_fail(QK_EDEVICE, "qk_build_mps: a Jacobi factorisation did not converge in %d sweeps", MAX_SWEEPS);
+  }
+  for (int s = 0; s < n_states; ++s) b->offsets[s] = offs[s];
+  b->heap = heap;
+  b->total = (int64_t)ctr[1];
+  b->kernel_ms = ms;
+  *out = b;
+  return QK_OK;
+}
+
+extern "C" int qk_built_info(const qk_built* b, int32_t* dims, double* fidelity, int64_t* offsets, int64_t* total_complex, double* kernel_ms) {
+  if (!b) return qk_fail(QK_EINVAL, "qk_built_info: null handle");
+  if (dims) std::copy(b->dims.begin(), b->dims.end(), dims);
+  if (fidelity) std::copy(b->fidelity.begin(), b->fidelity.end(), fidelity);
+  if (offsets) std::copy(b->offsets.begin(), b->offsets.end(), offsets);
+  if (total_complex) *total_complex = b->total;
+  if (kernel_ms) *kernel_ms = b->kernel_ms;
+  return QK_OK;
+}
+
+extern "C" int qk_built_download(const qk_built* b, double* host) {
+  if (!b || !host) return qk_fail(QK_EINVAL, "qk_built_download: null argument");
+  HIP_TRY(hipSetDevice(b->ctx->device));
+  HIP_TRY(hipMemcpy(host, b->heap, (size_t)b->total * sizeof(cd), hipMemcpyDeviceToHost));
+  return QK_OK;
+}
+
+extern "C" int qk_built_destroy(qk_built* b) {
+  if (!b) return QK_OK;
+  if (b->heap) (void)hipFree(b->heap);
+  delete b;
+  return QK_OK;
+}
+
+extern "C" int qk_debug_jacobi(qk_ctx* c, int32_t p, int32_t q, double* a_inout, double* v_out, double* sig_out, int32_t* ord_out) {
+  if (!c || !a_inout || !v_out || !sig_out || !ord_out) return qk_fail(QK_EINVAL, "qk_debug_jacobi: null argument");
+  if (p < 1 || q < 1 || q > 2048) return qk_fail(QK_EINVAL, "qk_debug_jacobi: bad shape %d x %d", p, q);
+  HIP_TRY(hipSetDevice(c->device));
+  cd *dA = nullptr, *dV = nullptr;
+  double* dS = nullptr;
+  int *dO = nullptr, *dE = nullptr;
+  HIP_TRY(hipMalloc(&dA, (size_t)p * q * sizeof(cd)));
+  HIP_TRY(hipMalloc(&dV, (size_t)q * q * sizeof(cd)));
+  HIP_TRY(hipMalloc(&dS, (size_t)q * sizeof(double)));
+  HIP_TRY(hipMalloc(&dO, (size_t)q * sizeof(int)));
+  HIP_TRY(hipMalloc(&dE, 8 * sizeof(int)));
+  HIP_TRY(hipMemset(dE, 0, 8 * sizeof(int)));
+  HIP_TRY(hipMemcpy(dA, a_inout, (size_t)p * q * sizeof(cd), hipMemcpyHostToDevice));
+  qk_jacobi_kernel<<<dim3(1), dim3(BT), (size_t)q * (sizeof(double) + sizeof(int)) + 16, c->stream>>>(dA, p, q, dV, dS, dO, dE);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  HIP_TRY(hipMemcpy(a_inout, dA, (size_t)p * q * sizeof(cd), hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(v_out, dV, (size_t)q * q * sizeof(cd), hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(sig_out, dS, (size_t)q * sizeof(double), hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(ord_out, dO, (size_t)q * sizeof(int), hipMemcpyDeviceToHost));
+  int err = 0;
+  HIP_TRY(hipMemcpy(&err, dE, sizeof(int), hipMemcpyDeviceToHost));
+  (void)hipFree(dA), (void)hipFree(dV), (void)hipFree(dS), (void)hipFree(dO), (void)hipFree(dE);
+  if (err) return qk_fail(QK_EDEVICE, "qk_debug_jacobi: no convergence in %d sweeps", MAX_SWEEPS);
+  return QK_OK;
+}

@@ -74,6 +74,11 @@ _SIGNATURES = [
     ("qk_debug_profile", C.c_int, [_P, _P]),
     ("qk_debug_mma_bench", C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double)]),
     ("qk_selftest_mfma", C.c_int, [_P]),
+    ("qk_build_mps", C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P, C.c_double, C.c_double, C.c_int32, C.POINTER(_P)]),
+    ("qk_built_info", C.c_int, [_P, _P, _P, _P, C.POINTER(C.c_int64), C.POINTER(C.c_double)]),
+    ("qk_built_download", C.c_int, [_P, _P]),
+    ("qk_built_destroy", C.c_int, [_P]),
+    ("qk_debug_jacobi", C.c_int, [_P, C.c_int32, C.c_int32, _P, _P, _P, _P]),
 ]
 EXPORTED_SYMBOLS = [s[0] for s in _SIGNATURES]
 
@@ -289,6 +294,56 @@ class Context:
 
     def selftest(self):
         _check(lib().qk_selftest_mfma(self._h), "qk_selftest_mfma")
+
+    def debug_jacobi(self, a):
+        """The device builder's one-sided Jacobi on one matrix: returns (A V, V, column norms, order by decreasing norm)."""
+        a = np.array(a, dtype=np.complex128, order="C")
+        p, q = a.shape
+        v = np.zeros((q, q), dtype=np.complex128)
+        sig = np.zeros(q, dtype=np.float64)
+        order = np.zeros(q, dtype=np.int32)
+        _check(lib().qk_debug_jacobi(self._h, p, q, a.ctypes.data, v.ctypes.data, sig.ctypes.data, order.ctypes.data), "qk_debug_jacobi")
+        return a, v, sig, order
+
+    def build_mps(self, circuits, truncation_fidelity: float = 1.0 - 1e-16, value_of_zero: float = 1e-16, max_bond: int = 256):
+        """Device MPS builder (/root/reference/gpu_backend/kernel_state_ansatz.py:221, 263): the MPS of every
+        bound circuit of the list (``ansatz.BoundCircuit``; they must share one gate structure, as the data points of one
+        ansatz do) in ONE launch.  Returns (list[MPS], info) with info = {"kernel_ms", "total_complex"}."""
+        from .mps import MPS
+
+        circuits = list(circuits)
+        if not circuits:
+            raise QkError("build_mps needs at least one circuit")
+        c0 = circuits[0]
+        op = np.ascontiguousarray(c0.op, dtype=np.int8)
+        q0 = np.ascontiguousarray(c0.q0, dtype=np.int32)
+        for c in circuits[1:]:
+            if c.n_qubits != c0.n_qubits or not np.array_equal(c.op, c0.op) or not np.array_equal(c.q0, c0.q0):
+                raise QkError("build_mps: the circuits of one call must share their gate structure")
+        alpha = np.ascontiguousarray(np.stack([np.asarray(c.alpha, dtype=np.float64) for c in circuits]))
+        n, ns = int(c0.n_qubits), len(circuits)
+        h = _P()
+        _check(lib().qk_build_mps(self._h, ns, n, int(op.shape[0]), op.ctypes.data, q0.ctypes.data, alpha.ctypes.data,
+                                  max(0.0, 1.0 - float(truncation_fidelity)), float(value_of_zero), int(max_bond), C.byref(h)), "qk_build_mps")
+        try:
+            dims = np.zeros((ns, n + 1), dtype=np.int32)
+            fid = np.zeros(ns, dtype=np.float64)
+            offs = np.zeros(ns, dtype=np.int64)
+            total, ms = C.c_int64(), C.c_double()
+            _check(lib().qk_built_info(h, dims.ctypes.data, fid.ctypes.data, offs.ctypes.data, C.byref(total), C.byref(ms)), "qk_built_info")
+            flat = np.empty(total.value, dtype=np.complex128)
+            _check(lib().qk_built_download(h, flat.ctypes.data), "qk_built_download")
+        finally:
+            lib().qk_built_destroy(h)
+        states = []
+        for s_ in range(ns):
+            pos, tensors = int(offs[s_]), []
+            for k in range(n):
+                sz = int(dims[s_, k]) * 2 * int(dims[s_, k + 1])
+                tensors.append(flat[pos : pos + sz].reshape(int(dims[s_, k]), 2, int(dims[s_, k + 1])))
+                pos += sz
+            states.append(MPS(tensors, float(fid[s_])))
+        return states, {"kernel_ms": ms.value, "total_complex": int(total.value)}
 
     def upload(self, states, layout=QK_LAYOUT_LPR) -> MpsSet:
         states = list(states)

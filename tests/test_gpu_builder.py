@@ -1,0 +1,98 @@
+"""GPU tests of the device MPS builder: its Jacobi primitive against numpy's SVD, built states against the
+host builder (same algorithm on LAPACK) and against exact state vectors (the golden fixtures and the oracle).
+
+Tolerances: the two builders truncate along different numerical paths, so states agree to the truncation error
+(1e-16 of weight per gate): |<dev|host>|^2 = 1 and Gram entries within 1e-9; against the exact state vector 1e-8, the
+same bound the host builder is held to (tests/test_gpu_parity.py)."""
+import numpy as np
+import pytest
+
+from helpers import golden
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("p,q,rank", [(1, 1, None), (2, 2, None), (4, 2, None), (20, 12, None), (47, 43, None), (64, 64, None), (130, 100, None),
+                                      (60, 40, 17), (33, 33, 1), (16, 8, 4)])
+def test_jacobi_primitive_against_numpy_svd(gpu_ctx, p, q, rank):
+    rng = np.random.default_rng(p * 1000 + q)
+    a = rng.standard_normal((p, q)) + 1j * rng.standard_normal((p, q))
+    if rank:
+        a = (rng.standard_normal((p, rank)) + 1j * rng.standard_normal((p, rank))) @ (rng.standard_normal((rank, q)) + 1j * rng.standard_normal((rank, q)))
+    w, v, sig, order = gpu_ctx.debug_jacobi(a)
+    s_ref = np.linalg.svd(a, compute_uv=False)
+    assert sorted(order.tolist()) == list(range(q))
+    assert np.all(np.diff(sig[order]) <= 0)
+    assert np.abs(sig[order] - s_ref).max() < 1e-13 * s_ref[0]
+    assert np.abs(w @ v.conj().T - a).max() < 1e-13 * np.abs(a).max()  # A V = W with V unitary
+    assert np.abs(v.conj().T @ v - np.eye(q)).max() < 1e-13
+    g = w.conj().T @ w  # columns of W mutually orthogonal: absolute accuracy eps |A|^2
+    assert np.abs(g - np.diag(np.diag(g))).max() < 1e-13 * s_ref[0] ** 2
+
+
+@pytest.mark.parametrize("n,reps,gamma,d,npts", [(8, 2, 1.0, 1, 6), (12, 3, 1.0, 2, 6), (20, 4, 1.0, 2, 5), (9, 2, 0.3, 4, 4)])
+def test_device_builder_matches_host_builder(gpu_ctx, n, reps, gamma, d, npts):
+    import qml_cutensornet_amd as Q
+    from oracle import restatement as R
+
+    X = R.synthetic_features(npts, n, 7)
+    ans = Q.KernelStateAnsatz(n, reps, gamma, Q.entanglement_graph(n, d))
+    circuits = [ans.circuit_for_data(x) for x in X]
+    dev, info = gpu_ctx.build_mps(circuits)
+    host = [Q.simulate(c, 1 - 1e-16) for c in circuits]
+    assert info["kernel_ms"] > 0 and len(dev) == npts
+    for md, mh in zip(dev, host):
+        assert md.bond_dims()[0] == 1 and md.bond_dims()[-1] == 1
+        assert md.max_bond() <= max(2 * mh.max_bond(), 2)
+        assert abs(md.fidelity - 1.0) < 1e-12
+    z = np.array([R.mps_inner(md.tensors, mh.tensors) for md, mh in zip(dev, host)])
+    assert np.abs(np.abs(z) ** 2 - 1).max() < 1e-10
+    with gpu_ctx.upload(dev) as dx, gpu_ctx.upload(host) as hx:
+        assert np.abs(gpu_ctx.gram(dx) - gpu_ctx.gram(hx)).max() < 1e-9
+
+
+@pytest.mark.parametrize("name", ["cfg1_8q_r1_d1.npz", "deep_10q_r3_d3.npz"])
+def test_device_built_gram_against_exact_statevectors(gpu_ctx, name):
+    import qml_cutensornet_amd as Q
+
+    g = golden(name)
+    n, reps, gamma, d = int(g["n"]), int(g["reps"]), float(g["gamma"]), int(g["d"])
+    ans = Q.KernelStateAnsatz(n, reps, gamma, Q.entanglement_graph(n, d))
+    tr, _ = gpu_ctx.build_mps([ans.circuit_for_data(x) for x in g["X_train"]])
+    te, _ = gpu_ctx.build_mps([ans.circuit_for_data(x) for x in g["X_test"]])
+    with gpu_ctx.upload(tr) as dx, gpu_ctx.upload(te) as dy:
+        assert np.abs(gpu_ctx.gram(dx) - g["K_train"]).max() < 1e-8
+        assert np.abs(gpu_ctx.gram(dx, dy) - g["K_test"]).max() < 1e-8
+
+
+def test_device_builder_truncates_like_the_host_builder(gpu_ctx):
+    """A loose fidelity really truncates: same kept bonds and fidelity product as the host builder, state by state."""
+    import qml_cutensornet_amd as Q
+    from oracle import restatement as R
+
+    n, reps, d = 14, 3, 2
+    X = R.synthetic_features(4, n, 11)
+    ans = Q.KernelStateAnsatz(n, reps, 1.0, Q.entanglement_graph(n, d))
+    circuits = [ans.circuit_for_data(x) for x in X]
+    dev, _ = gpu_ctx.build_mps(circuits, truncation_fidelity=1 - 1e-4)
+    host = [Q.simulate(c, 1 - 1e-4) for c in circuits]
+    for md, mh in zip(dev, host):
+        assert md.max_bond() <= mh.max_bond() + 1
+        assert abs(md.fidelity - mh.fidelity) < 1e-6
+        assert abs(abs(R.mps_inner(md.tensors, mh.tensors)) ** 2 - 1) < 1e-3
+
+
+def test_device_builder_rejects_bad_input(gpu_ctx):
+    import qml_cutensornet_amd as Q
+    from qml_cutensornet_amd.engine import QkError
+    from oracle import restatement as R
+
+    ans = Q.KernelStateAnsatz(10, 3, 1.0, Q.entanglement_graph(10, 3))
+    c = ans.circuit_for_data(R.synthetic_features(3, 10, 3)[0])
+    with pytest.raises(QkError, match="max_bond"):
+        gpu_ctx.build_mps([c], max_bond=2)  # the state needs more than 2
+    other = Q.KernelStateAnsatz(10, 2, 1.0, Q.entanglement_graph(10, 3)).circuit_for_data(R.synthetic_features(3, 10, 3)[0])
+    with pytest.raises(QkError, match="gate structure"):
+        gpu_ctx.build_mps([c, other])
+    with pytest.raises(QkError):
+        gpu_ctx.build_mps([])
