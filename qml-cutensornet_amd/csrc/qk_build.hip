@@ -22,8 +22,14 @@
 
 namespace {
 typedef double2 cd;
-constexpr int BT = 512;       // threads per workgroup
-constexpr int GL = 16;        // lanes that share one column pair
+#ifndef QK_BUILD_BT
+#define QK_BUILD_BT 256
+#endif
+constexpr int BT = QK_BUILD_BT;  // threads per workgroup (4 wavefronts, one per SIMD; 512 x 16 lanes per pair measured 1.3x slower)
+#ifndef QK_BUILD_GL
+#define QK_BUILD_GL 8
+#endif
+constexpr int GL = QK_BUILD_GL;  // lanes that share one column pair
 constexpr int NG = BT / GL;   // column pairs per step
 constexpr int MAX_SWEEPS = 40;
 enum { OP_H = 0, OP_RZ = 1, OP_XX = 2, OP_SWAP = 3 };  // ansatz.py
@@ -63,7 +69,12 @@ struct WgShared {
 // (q x q, row-major) holds the accumulated unitary; sig[j] = |column j|, ord = column indices by decreasing sig.
 __device__ void jacobi_orth(cd* A, const long rs, const long cs, const int p, const int q, cd* V, const int ldv,
                             double* sig, int* ord, WgShared* sh, int* error) {
-  const int tid = threadIdx.x, grp = tid / GL, gl = tid % GL;
+  const int tid = threadIdx.x, gl = tid % GL;
+#ifdef QK_BUILD_SPREAD  // consecutive pairs go to different wavefronts
+  const int grp = ((tid % 64) / GL) * (BT / 64) + tid / 64;
+#else
+  const int grp = tid / GL;
+#endif
   for (int e = tid; e < q * q; e += BT) V[(e / q) * ldv + e % q] = cd{(e / q == e % q) ? 1.0 : 0.0, 0.0};
   const double tol2 = 1e-30 * (double)max(p, 10);  // (eps sqrt(p))^2-ish: the rounding floor of a length-p inner product
   for (int jc = grp; jc < q; jc += NG) {  // squared Frobenius norm (sets the absolute floor of the rotation test)
@@ -88,8 +99,10 @@ __device__ void jacobi_orth(cd* A, const long rs, const long cs, const int p, co
       __syncthreads();
       for (int r = 0; r < nr; ++r) {
         for (int k = grp; k < half; k += NG) {
-          int c1 = (k == 0) ? nr : (r + k) % nr;
-          int c2 = (k == 0) ? r : (r - k + nr) % nr;
+          int c1 = r + k, c2 = r - k;  // round-robin tournament: (nr, r) and ((r + k) mod nr, (r - k) mod nr), k = 1..half-1
+          if (c1 >= nr) c1 -= nr;
+          if (c2 < 0) c2 += nr;
+          if (k == 0) c1 = nr, c2 = r;
           if (c1 < q && c2 < q) {
             if (c1 > c2) {
               const int t_ = c1;
@@ -117,11 +130,11 @@ __device__ void jacobi_orth(cd* A, const long rs, const long cs, const int p, co
             // the columns that carry weight, the absolute accuracy of a LAPACK SVD (eps |A|) for the short ones -- whose
             // directions are rounding noise of the products that made A and would never settle under the relative test
             if (g2 > tol2 * fmax(al, be) * fmax(fmin(al, be), 1e-3 * frob)) {
-              const double ga = sqrt(g2);
-              const double zeta = (be - al) / (2.0 * ga);
+              const double iga = rsqrt(g2);                  // 1 / |<a1, a2>|
+              const double zeta = 0.5 * (be - al) * iga;
               const double t = copysign(1.0, zeta) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
-              const double c = 1.0 / sqrt(1.0 + t * t), s = c * t;
-              const double phr = gr / ga, phi = gi / ga;  // e^{i phi}
+              const double c = rsqrt(1.0 + t * t), s = c * t;
+              const double phr = gr * iga, phi = gi * iga;  // e^{i phi}
               const cd s1 = cd{-s * phr, s * phi};        // -s conj(ph)
               const cd s2 = cd{s * phr, s * phi};         //  s ph
               for (int i = gl; i < p; i += GL) {
@@ -531,12 +544,13 @@ extern "C" int qk_build_mps(qk_ctx* c, int32_t n_states, int32_t n_qubits, int32
   size_t lds_meta = (size_t)2 * cap * sizeof(double) + (size_t)2 * cap * sizeof(int) + (size_t)(n_qubits + 1) * sizeof(int);
   lds_meta = (lds_meta + 15) / 16 * 16;
   if (lds_meta > 24 * 1024) return qk_fail(QK_EINVAL, "qk_build_mps: %d qubits at max_bond %d need %zu bytes of LDS", n_qubits, cap, lds_meta);
-  size_t lds_total = 156 * 1024;  // one workgroup per CU: the rest of the 160 KiB is the Jacobi working set
+  size_t lds_total = 76 * 1024;  // two workgroups per CU; what the bookkeeping leaves is the Jacobi working set (A and V of a
+                                 // factorisation up to ~(p + q) q = 4500 complex numbers, e.g. 74 x 37; larger ones run from L2)
   if (const char* v = std::getenv("QK_BUILD_LDS_KB")) lds_total = (size_t)std::max(32, std::min(156, std::atoi(v))) * 1024;
   const int jl_elems = (int)((lds_total - lds_meta) / sizeof(cd));
   const size_t lds = lds_total;
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(qk_build_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  const int wgs_per_cu = (lds_total <= 76 * 1024) ? 2 : 1;
+  const int wgs_per_cu = (int)std::min<size_t>(4, (160 * 1024) / (lds_total + 1024));  // + the static LDS of the kernel
   size_t free_b = 0, total_b = 0;
   HIP_TRY(hipMemGetInfo(&free_b, &total_b));
   const size_t per_wg = ((size_t)n_qubits * 2 * cap * cap + (size_t)3 * 4 * cap * cap) * sizeof(cd);
