@@ -191,6 +191,9 @@ int qk_build_mps(qk_ctx* ctx, int32_t n_states, int32_t n_qubits, int32_t n_ops,
 int qk_built_info(const qk_built* built, int32_t* dims, double* fidelity, int64_t* offsets, int64_t* total_complex,
                   double* kernel_ms);
 int qk_built_download(const qk_built* built, double* host /* 2 * total_complex doubles (re, im interleaved) */);
+/* The built states as a set of the Gram engine (the image qk_mps_set_create makes from host tensors), packed on the
+ * device: nothing crosses PCIe between the builder and the sweep.  The set is independent of `built` afterwards.  */
+int qk_mps_set_from_built(qk_ctx* ctx, const qk_built* built, qk_mps_set** out);
 int qk_built_destroy(qk_built* built);
 /* Diagnostic: the builder's Jacobi primitive on one host matrix a[p][q] (complex128 row-major, overwritten by A V);
  * v_out[q][q], sig_out[q] = column norms of A V, ord_out[q] = columns by decreasing norm.                          */

@@ -508,6 +508,25 @@ __global__ __launch_bounds__(BT) void qk_build_kernel(const BuildArgs g) {
   }
 }
 
+// Built states -> the Gram engine's set image: site (s, k) of the heap ([l][2][r] complex, interleaved) becomes two planes
+// [pad16(l)][2][pad16(r)] (re, im) in a zero-initialised allocation (the layout of qk_pack_state, qkgram.hip).
+__global__ __launch_bounds__(256) void qk_pack_built_kernel(const cd* __restrict__ heap, const long long* __restrict__ src_offs,
+                                                            const long long* __restrict__ dst_offs, const int32_t* __restrict__ dims_true,
+                                                            const int32_t* __restrict__ dims_pad, int n_sites, double* __restrict__ data) {
+  const int s = blockIdx.x / n_sites, k = blockIdx.x - s * n_sites;
+  const int cl = dims_true[(long)s * (n_sites + 1) + k], cr = dims_true[(long)s * (n_sites + 1) + k + 1];
+  const int pl = dims_pad[(long)s * (n_sites + 1) + k], pr = dims_pad[(long)s * (n_sites + 1) + k + 1];
+  const cd* src = heap + src_offs[blockIdx.x];
+  double* re = data + dst_offs[blockIdx.x];
+  double* im = re + (long)pl * 2 * pr;
+  for (int e = threadIdx.x; e < cl * 2 * cr; e += 256) {
+    const int row = e / cr, c = e - row * cr;
+    const cd v = src[e];
+    re[(long)row * pr + c] = v.x;
+    im[(long)row * pr + c] = v.y;
+  }
+}
+
 // ---- debug: one Jacobi factorisation of a host matrix (tests the primitive on its own)
 __global__ __launch_bounds__(BT) void qk_jacobi_kernel(cd* A, int p, int q, cd* V, double* sig_out, int* ord_out, int* error) {
   extern __shared__ double sh_raw[];
@@ -666,6 +685,60 @@ extern "C" int qk_built_download(const qk_built* b, double* host) {
   if (!b || !host) return qk_fail(QK_EINVAL, "qk_built_download: null argument");
   HIP_TRY(hipSetDevice(b->ctx->device));
   HIP_TRY(hipMemcpy(host, b->heap, (size_t)b->total * sizeof(cd), hipMemcpyDeviceToHost));
+  return QK_OK;
+}
+
+extern "C" int qk_mps_set_from_built(qk_ctx* c, const qk_built* b, qk_mps_set** out) {
+  if (!c || !b || !out) return qk_fail(QK_EINVAL, "qk_mps_set_from_built: null argument");
+  if (b->ctx != c) return qk_fail(QK_EINVAL, "qk_mps_set_from_built: the states were built in another context");
+  HIP_TRY(hipSetDevice(c->device));
+  const int ns = b->n_states, n = b->n_qubits, stride = n + 1;
+  auto pad16 = [](int x) { return (x + 15) / 16 * 16; };
+  std::vector<int32_t> pad((size_t)ns * stride);
+  std::vector<long long> src((size_t)ns * n), dst((size_t)ns * n);
+  long long total = 0;
+  int max_pad = 0;
+  for (int s = 0; s < ns; ++s) {
+    long long pos = b->offsets[s];
+    for (int k = 0; k <= n; ++k) {
+      pad[(size_t)s * stride + k] = pad16(b->dims[(size_t)s * stride + k]);
+      max_pad = std::max(max_pad, pad[(size_t)s * stride + k]);
+    }
+    for (int k = 0; k < n; ++k) {
+      src[(size_t)s * n + k] = pos;
+      dst[(size_t)s * n + k] = total;
+      pos += 2ll * b->dims[(size_t)s * stride + k] * b->dims[(size_t)s * stride + k + 1];
+      total += 2ll * pad[(size_t)s * stride + k] * 2 * pad[(size_t)s * stride + k + 1];
+    }
+  }
+  qk_mps_set* m = new qk_mps_set;
+  m->ctx = c, m->n_states = ns, m->n_sites = n, m->max_pad = max_pad;
+  m->dims_true = b->dims;
+  m->bytes = total * (long long)sizeof(double);
+  long long* d_src = nullptr;
+  hipError_t e = hipMalloc(&m->d_data, (size_t)m->bytes);
+  if (e == hipSuccess) e = hipMemsetAsync(m->d_data, 0, (size_t)m->bytes, c->stream);
+  if (e == hipSuccess) e = hipMalloc(&m->d_dims, pad.size() * sizeof(int32_t));
+  if (e == hipSuccess) e = hipMalloc(&m->d_true, pad.size() * sizeof(int32_t));
+  if (e == hipSuccess) e = hipMalloc(&m->d_offs, dst.size() * sizeof(int64_t));
+  if (e == hipSuccess) e = hipMalloc(&d_src, src.size() * sizeof(long long));
+  if (e == hipSuccess) e = hipMemcpyAsync(m->d_dims, pad.data(), pad.size() * sizeof(int32_t), hipMemcpyHostToDevice, c->stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(m->d_true, b->dims.data(), pad.size() * sizeof(int32_t), hipMemcpyHostToDevice, c->stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(m->d_offs, dst.data(), dst.size() * sizeof(long long), hipMemcpyHostToDevice, c->stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(d_src, src.data(), src.size() * sizeof(long long), hipMemcpyHostToDevice, c->stream);
+  if (e == hipSuccess) {
+    qk_pack_built_kernel<<<dim3((unsigned)(ns * n)), dim3(256), 0, c->stream>>>(b->heap, d_src, reinterpret_cast<const long long*>(m->d_offs), m->d_true,
+                                                                              m->d_dims, n, m->d_data);
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+  (void)hipFree(d_src);
+  if (e != hipSuccess) {
+    (void)hipFree(m->d_data), (void)hipFree(m->d_dims), (void)hipFree(m->d_true), (void)hipFree(m->d_offs);
+    delete m;
+    return qk_fail(QK_EDEVICE, "qk_mps_set_from_built: %s", hipGetErrorString(e));
+  }
+  *out = m;
   return QK_OK;
 }
 

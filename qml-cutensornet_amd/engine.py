@@ -78,6 +78,7 @@ _SIGNATURES = [
     ("qk_built_info", C.c_int, [_P, _P, _P, _P, C.POINTER(C.c_int64), C.POINTER(C.c_double)]),
     ("qk_built_download", C.c_int, [_P, _P]),
     ("qk_built_destroy", C.c_int, [_P]),
+    ("qk_mps_set_from_built", C.c_int, [_P, _P, C.POINTER(_P)]),
     ("qk_debug_jacobi", C.c_int, [_P, C.c_int32, C.c_int32, _P, _P, _P, _P]),
 ]
 EXPORTED_SYMBOLS = [s[0] for s in _SIGNATURES]
@@ -344,6 +345,33 @@ class Context:
                 pos += sz
             states.append(MPS(tensors, float(fid[s_])))
         return states, {"kernel_ms": ms.value, "total_complex": int(total.value)}
+
+    def build_mps_set(self, circuits, truncation_fidelity: float = 1.0 - 1e-16, value_of_zero: float = 1e-16, max_bond: int = 256):
+        """Like ``build_mps`` but the states never leave the device: returns (MpsSet, info) with info = {"kernel_ms", "dims",
+        "fidelity"}; the set feeds ``gram`` / ``gram_values`` directly."""
+        circuits = list(circuits)
+        if not circuits:
+            raise QkError("build_mps_set needs at least one circuit")
+        c0 = circuits[0]
+        op = np.ascontiguousarray(c0.op, dtype=np.int8)
+        q0 = np.ascontiguousarray(c0.q0, dtype=np.int32)
+        for c in circuits[1:]:
+            if c.n_qubits != c0.n_qubits or not np.array_equal(c.op, c0.op) or not np.array_equal(c.q0, c0.q0):
+                raise QkError("build_mps_set: the circuits of one call must share their gate structure")
+        alpha = np.ascontiguousarray(np.stack([np.asarray(c.alpha, dtype=np.float64) for c in circuits]))
+        n, ns = int(c0.n_qubits), len(circuits)
+        h, hs = _P(), _P()
+        _check(lib().qk_build_mps(self._h, ns, n, int(op.shape[0]), op.ctypes.data, q0.ctypes.data, alpha.ctypes.data,
+                                  max(0.0, 1.0 - float(truncation_fidelity)), float(value_of_zero), int(max_bond), C.byref(h)), "qk_build_mps")
+        try:
+            dims = np.zeros((ns, n + 1), dtype=np.int32)
+            fid = np.zeros(ns, dtype=np.float64)
+            ms = C.c_double()
+            _check(lib().qk_built_info(h, dims.ctypes.data, fid.ctypes.data, None, None, C.byref(ms)), "qk_built_info")
+            _check(lib().qk_mps_set_from_built(self._h, h, C.byref(hs)), "qk_mps_set_from_built")
+        finally:
+            lib().qk_built_destroy(h)
+        return MpsSet(self, hs, dims), {"kernel_ms": ms.value, "dims": dims, "fidelity": fid}
 
     def upload(self, states, layout=QK_LAYOUT_LPR) -> MpsSet:
         states = list(states)

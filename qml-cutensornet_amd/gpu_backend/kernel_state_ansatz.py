@@ -46,9 +46,21 @@ def _say(is_root, text):
 
 def _simulate_share(ansatz, points, rank, n_procs, fidelity, is_root, label):
     """This rank's slice of the data set -> MPS (contiguous chunks of ceil(N/P), as ref :154,:171-174)."""
+    import os
+
     per_rank = -(-len(points) // n_procs)
     lo = min(len(points), rank * per_rank)
     hi = min(len(points), lo + per_rank)
+    if os.environ.get("QK_BUILDER", "host") == "device" and hi > lo:
+        # the rank's whole share in ONE launch of the device builder (csrc/qk_build.hip): what the reference does with
+        # simulate(libhandle, ...) on the rank's GPU (ref :221,:263).  Pays off at the small bonds of the reference's own
+        # runs (profiles/r01/device_builder_bench.txt); the host builder stays the default.
+        t0 = time.perf_counter()
+        states, _ = _engine.default_context().build_mps([ansatz.circuit_for_data(points[k, :]) for k in range(lo, hi)], fidelity,
+                                                        max_bond=int(os.environ.get("QK_BUILDER_MAX_BOND", "256")))
+        dt = (time.perf_counter() - t0) / (hi - lo)
+        _say(is_root, f"{label}: 100%")
+        return lo, states, [dt] * (hi - lo)
     states, secs = [], []
     tick = max(1, per_rank // 10)
     for k in range(lo, hi):
