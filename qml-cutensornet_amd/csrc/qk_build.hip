@@ -66,16 +66,17 @@ struct WgShared {
 };
 
 // One-sided Jacobi.  A is p x q, element (i, j) at A[i * rs + j * cs].  On return A <- A V with mutually orthogonal columns and V
-// (q x q, row-major) holds the accumulated unitary; sig[j] = |column j|, ord = column indices by decreasing sig.
-__device__ void jacobi_orth(cd* A, const long rs, const long cs, const int p, const int q, cd* V, const int ldv,
-                            double* sig, int* ord, WgShared* sh, int* error) {
+// (q x q, element (i, c) at V[i * vrs + c * vcs]) holds the accumulated unitary; sig[j] = |column j|, ord = column indices by decreasing sig.
+__device__ void jacobi_orth(cd* A, const long rs, const long cs, const int p, const int q, cd* V, const int vrs, const int vcs,
+                            double* sig, int* ord, WgShared* sh, int* error, const bool init_v = true) {
   const int tid = threadIdx.x, gl = tid % GL;
 #ifdef QK_BUILD_SPREAD  // consecutive pairs go to different wavefronts
   const int grp = ((tid % 64) / GL) * (BT / 64) + tid / 64;
 #else
   const int grp = tid / GL;
 #endif
-  for (int e = tid; e < q * q; e += BT) V[(e / q) * ldv + e % q] = cd{(e / q == e % q) ? 1.0 : 0.0, 0.0};
+  if (init_v)
+    for (int e = tid; e < q * q; e += BT) V[(e / q) * vrs + (e % q) * vcs] = cd{(e / q == e % q) ? 1.0 : 0.0, 0.0};
   const double tol2 = 1e-30 * (double)max(p, 10);  // (eps sqrt(p))^2-ish: the rounding floor of a length-p inner product
   for (int jc = grp; jc < q; jc += NG) {  // squared Frobenius norm (sets the absolute floor of the rotation test)
     double al = 0;
@@ -142,10 +143,12 @@ __device__ void jacobi_orth(cd* A, const long rs, const long cs, const int p, co
                 a1[i * rs] = cfma(s1, y, cd{c * x.x, c * x.y});
                 a2[i * rs] = cfma(s2, x, cd{c * y.x, c * y.y});
               }
+              cd* v1 = V + c1 * vcs;
+              cd* v2 = V + c2 * vcs;
               for (int i = gl; i < q; i += GL) {
-                const cd x = V[i * ldv + c1], y = V[i * ldv + c2];
-                V[i * ldv + c1] = cfma(s1, y, cd{c * x.x, c * x.y});
-                V[i * ldv + c2] = cfma(s2, x, cd{c * y.x, c * y.y});
+                const cd x = v1[i * vrs], y = v2[i * vrs];
+                v1[i * vrs] = cfma(s1, y, cd{c * x.x, c * x.y});
+                v2[i * vrs] = cfma(s2, x, cd{c * y.x, c * y.y});
               }
               sh->flag = 1;
             }
@@ -191,17 +194,54 @@ __device__ void jacobi_orth(cd* A, const long rs, const long cs, const int p, co
 // that the 16 lanes of a pair hit 16 different banks): a step is then a few hundred cycles instead of a store-drain +
 // L2 round trip.  Results are copied back to the global A (same strides) and to V (row-major, ld q).
 __device__ void jacobi_auto(cd* A, const long rs, const long cs, const int p, const int q, cd* V, double* sig, int* ord, WgShared* sh,
-                            int* error, cd* lds, const int lds_elems) {
+                            int* error, cd* lds, const int lds_elems, cd* scratch) {
   const int ld = q | 1;
   if ((long)(p + q) * ld <= lds_elems) {
     cd* LA = lds;
     cd* LV = lds + (long)p * ld;
+#ifndef QK_BUILD_NO_SORT  // de Rijk: start from the columns in order of decreasing norm (V starts as that permutation)
+    {
+      const int grp = threadIdx.x / GL, gl = threadIdx.x % GL;
+      for (int jc = grp; jc < q; jc += NG) {
+        double al = 0;
+        for (int i = gl; i < p; i += GL) {
+          const cd x = A[i * rs + jc * cs];
+          al += x.x * x.x + x.y * x.y;
+        }
+#pragma unroll
+        for (int m = GL / 2; m > 0; m >>= 1) al += __shfl_xor(al, m, GL);
+        sig[jc] = al;
+      }
+      __syncthreads();
+      for (int jc = threadIdx.x; jc < q; jc += BT) {
+        const double v = sig[jc];
+        int rank = 0;
+        for (int i = 0; i < q; ++i) {
+          const double u = sig[i];
+          rank += (u > v) || (u == v && i < jc);
+        }
+        ord[jc] = rank;  // column jc goes to position rank
+      }
+      __syncthreads();
+      for (int e = threadIdx.x; e < p * q; e += BT) {
+        const int i = e / q, jc = e - i * q;
+        LA[i * ld + ord[jc]] = A[i * rs + jc * cs];
+      }
+      for (int e = threadIdx.x; e < q * q; e += BT) {
+        const int i = e / q, jc = e - i * q;
+        LV[i * ld + jc] = cd{(ord[i] == jc) ? 1.0 : 0.0, 0.0};
+      }
+      __syncthreads();
+    }
+    jacobi_orth(LA, ld, 1, p, q, LV, ld, 1, sig, ord, sh, error, false);
+#else
     for (int e = threadIdx.x; e < p * q; e += BT) {
       const int i = e / q, jc = e - i * q;
       LA[i * ld + jc] = A[i * rs + jc * cs];
     }
     __syncthreads();
-    jacobi_orth(LA, ld, 1, p, q, LV, ld, sig, ord, sh, error);
+    jacobi_orth(LA, ld, 1, p, q, LV, ld, 1, sig, ord, sh, error);
+#endif
     for (int e = threadIdx.x; e < p * q; e += BT) {
       const int i = e / q, jc = e - i * q;
       A[i * rs + jc * cs] = LA[i * ld + jc];
@@ -212,7 +252,38 @@ __device__ void jacobi_auto(cd* A, const long rs, const long cs, const int p, co
     }
     __syncthreads();
   } else {
-    jacobi_orth(A, rs, cs, p, q, V, q, sig, ord, sh, error);
+    // from the L2-resident workspace: columns contiguous (a pair's 8 lanes read whole cache lines), for A through a
+    // column-major copy in `scratch` when its columns are strided, for V by accumulating V^T and transposing at the end
+#ifndef QK_BUILD_NO_COLMAJOR
+    cd* S = A;
+    long srs = rs, scs = cs;
+    if (rs != 1) {
+      for (int e = threadIdx.x; e < p * q; e += BT) {
+        const int i = e / q, jc = e - i * q;
+        scratch[(long)jc * p + i] = A[i * rs + jc * cs];
+      }
+      __syncthreads();
+      S = scratch, srs = 1, scs = p;
+    }
+    jacobi_orth(S, srs, scs, p, q, V, 1, q, sig, ord, sh, error);
+    if (rs != 1) {
+      for (int e = threadIdx.x; e < p * q; e += BT) {
+        const int i = e / q, jc = e - i * q;
+        A[i * rs + jc * cs] = scratch[(long)jc * p + i];
+      }
+    }
+    for (int e = threadIdx.x; e < q * q; e += BT) {  // V^T -> V in place
+      const int i = e / q, jc = e - i * q;
+      if (i < jc) {
+        const cd a = V[i * q + jc], b = V[jc * q + i];
+        V[i * q + jc] = b;
+        V[jc * q + i] = a;
+      }
+    }
+    __syncthreads();
+#else
+    jacobi_orth(A, rs, cs, p, q, V, q, 1, sig, ord, sh, error);
+#endif
   }
 }
 
@@ -324,7 +395,7 @@ __global__ __launch_bounds__(BT) void qk_build_kernel(const BuildArgs g) {
         cd* u = sites + (centre + 1) * slot;
         const int l = dims[centre], r = dims[centre + 1], r2 = dims[centre + 2];
         const int m = 2 * l;
-        jacobi_auto(t, r, 1, m, r, VV, sig, ord, &sh, g.error, jl, g.jl_elems);
+        jacobi_auto(t, r, 1, m, r, VV, sig, ord, &sh, g.error, jl, g.jl_elems, TMP);
         if (tid == 0) {
           int k = 0;
           const double smax = sig[ord[0]];
@@ -365,7 +436,7 @@ __global__ __launch_bounds__(BT) void qk_build_kernel(const BuildArgs g) {
         const int l = dims[centre], r = dims[centre + 1], l0 = dims[centre - 1];
         const int w = 2 * r;
         // A(i = (p, c), j = a) = t[a][i]: rs = 1, cs = w
-        jacobi_auto(t, 1, w, w, l, VV, sig, ord, &sh, g.error, jl, g.jl_elems);
+        jacobi_auto(t, 1, w, w, l, VV, sig, ord, &sh, g.error, jl, g.jl_elems, TMP);
         if (tid == 0) {
           int k = 0;
           const double smax = sig[ord[0]];
@@ -430,8 +501,8 @@ __global__ __launch_bounds__(BT) void qk_build_kernel(const BuildArgs g) {
       // ---- SVD of theta[m x nn] by one-sided Jacobi on its smaller side
       const bool cols = (nn <= m);
       const int qd = cols ? nn : m;
-      if (cols) jacobi_auto(TH, nn, 1, m, nn, VV, sig, ord, &sh, g.error, jl, g.jl_elems);
-      else jacobi_auto(TH, 1, nn, nn, m, VV, sig, ord, &sh, g.error, jl, g.jl_elems);
+      if (cols) jacobi_auto(TH, nn, 1, m, nn, VV, sig, ord, &sh, g.error, jl, g.jl_elems, TMP);
+      else jacobi_auto(TH, 1, nn, nn, m, VV, sig, ord, &sh, g.error, jl, g.jl_elems, TMP);
       wg_kept(sig, ord, qd, g.budget, g.zero, &sh);
       int keep = sh.keep;
       fidelity *= sh.frac;
@@ -533,7 +604,7 @@ __global__ __launch_bounds__(BT) void qk_jacobi_kernel(cd* A, int p, int q, cd* 
   double* sig = sh_raw;
   int* ord = reinterpret_cast<int*>(sig + q);
   __shared__ WgShared sh;
-  jacobi_orth(A, q, 1, p, q, V, q, sig, ord, &sh, error);
+  jacobi_orth(A, q, 1, p, q, V, q, 1, sig, ord, &sh, error);
   for (int e = threadIdx.x; e < q; e += BT) {
     sig_out[e] = sig[e];
     ord_out[e] = ord[e];
