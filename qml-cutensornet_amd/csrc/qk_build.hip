@@ -19,9 +19,10 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 
 namespace {
-typedef double2 cd;
+typedef double cd __attribute__((ext_vector_type(2)));  // complex128 as (re, im); a native vector so that LDS-typed pointers work
 #ifndef QK_BUILD_BT
 #define QK_BUILD_BT 256
 #endif
@@ -37,6 +38,23 @@ enum { ERR_BOND = 1, ERR_HEAP = 2, ERR_SWEEPS = 4, ERR_GATE = 8 };
 
 __device__ __forceinline__ cd cmul(const cd a, const cd b) { return cd{a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x}; }
 __device__ __forceinline__ cd cfma(const cd a, const cd b, const cd c) { return cd{c.x + a.x * b.x - a.y * b.y, c.y + a.x * b.y + a.y * b.x}; }
+
+// Sum over the GL lanes of a pair group with DPP lane permutations (quad swaps, then half-row / row mirrors): a handful of
+// VALU moves instead of the LDS round trip of a ds_bpermute per 32-bit half and stage.
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(const double v) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xF, 0xF, true);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xF, 0xF, true);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double group_sum(double v) {
+  static_assert(GL == 8 || GL == 16, "group_sum is written for 8 or 16 lanes per pair");
+  v += dpp_f64<0xB1>(v);   // quad_perm [1,0,3,2]: lane ^ 1
+  v += dpp_f64<0x4E>(v);   // quad_perm [2,3,0,1]: lane ^ 2
+  v += dpp_f64<0x141>(v);  // row_half_mirror: the other quad of the 8
+  if (GL == 16) v += dpp_f64<0x140>(v);  // row_mirror: the other half of the 16
+  return v;
+}
 
 struct BuildArgs {
   int n_states, n_qubits, n_ops, cap;
@@ -63,11 +81,14 @@ struct WgShared {
   int flag, keep, state, pad;
   double frac, nrm;
   unsigned long long off;
+  unsigned long long worst;  // bits of the largest squared relative inner product rotated in the current sweep
 };
 
 // One-sided Jacobi.  A is p x q, element (i, j) at A[i * rs + j * cs].  On return A <- A V with mutually orthogonal columns and V
 // (q x q, element (i, c) at V[i * vrs + c * vcs]) holds the accumulated unitary; sig[j] = |column j|, ord = column indices by decreasing sig.
-__device__ void jacobi_orth(cd* A, const long rs, const long cs, const int p, const int q, cd* V, const int vrs, const int vcs,
+typedef __attribute__((address_space(3))) cd* lds_cd_ptr;  // LDS-typed: ds_read/ds_write instead of flat accesses
+template <typename P>  // P = cd* (L2-resident workspace) or lds_cd_ptr
+__device__ void jacobi_orth(P A, const long rs, const long cs, const int p, const int q, P V, const int vrs, const int vcs,
                             double* sig, int* ord, WgShared* sh, int* error, const bool init_v = true) {
   const int tid = threadIdx.x, gl = tid % GL;
 #ifdef QK_BUILD_SPREAD  // consecutive pairs go to different wavefronts
@@ -77,15 +98,14 @@ __device__ void jacobi_orth(cd* A, const long rs, const long cs, const int p, co
 #endif
   if (init_v)
     for (int e = tid; e < q * q; e += BT) V[(e / q) * vrs + (e % q) * vcs] = cd{(e / q == e % q) ? 1.0 : 0.0, 0.0};
-  const double tol2 = 1e-30 * (double)max(p, 10);  // (eps sqrt(p))^2-ish: the rounding floor of a length-p inner product
+  const double tol2 = 1e-29 * (double)max(p, 10);  // (1e-14 sqrt(p / 10))^2: a decade above the rounding floor of a length-p inner product
   for (int jc = grp; jc < q; jc += NG) {  // squared Frobenius norm (sets the absolute floor of the rotation test)
     double al = 0;
     for (int i = gl; i < p; i += GL) {
       const cd x = A[i * rs + jc * cs];
       al += x.x * x.x + x.y * x.y;
     }
-#pragma unroll
-    for (int m = GL / 2; m > 0; m >>= 1) al += __shfl_xor(al, m, GL);
+    al = group_sum(al);
     sig[jc] = al;
   }
   __syncthreads();
@@ -95,8 +115,9 @@ __device__ void jacobi_orth(cd* A, const long rs, const long cs, const int p, co
   if (q >= 2) {
     const int qe = q + (q & 1), half = qe / 2, nr = qe - 1;
     int sweep = 0;
+    const long long t_begin = wall_clock64();
     for (; sweep < MAX_SWEEPS; ++sweep) {
-      if (tid == 0) sh->flag = 0;
+      if (tid == 0) sh->flag = 0, sh->worst = 0ull;
       __syncthreads();
       for (int r = 0; r < nr; ++r) {
         for (int k = grp; k < half; k += NG) {
@@ -109,8 +130,8 @@ __device__ void jacobi_orth(cd* A, const long rs, const long cs, const int p, co
               const int t_ = c1;
               c1 = c2, c2 = t_;
             }
-            cd* a1 = A + c1 * cs;
-            cd* a2 = A + c2 * cs;
+            P a1 = A + c1 * cs;
+            P a2 = A + c2 * cs;
             double al = 0, be = 0, gr = 0, gi = 0;
             for (int i = gl; i < p; i += GL) {
               const cd x = a1[i * rs], y = a2[i * rs];
@@ -119,18 +140,14 @@ __device__ void jacobi_orth(cd* A, const long rs, const long cs, const int p, co
               gr += x.x * y.x + x.y * y.y;  // conj(x) * y
               gi += x.x * y.y - x.y * y.x;
             }
-#pragma unroll
-            for (int m = GL / 2; m > 0; m >>= 1) {
-              al += __shfl_xor(al, m, GL);
-              be += __shfl_xor(be, m, GL);
-              gr += __shfl_xor(gr, m, GL);
-              gi += __shfl_xor(gi, m, GL);
-            }
+            al = group_sum(al), be = group_sum(be), gr = group_sum(gr), gi = group_sum(gi);
             const double g2 = gr * gr + gi * gi;
             // rotate when |<a1, a2>| > tol |a1| max(|a2|, 0.03 |A|_F), a1 the longer column: relative orthogonality for
             // the columns that carry weight, the absolute accuracy of a LAPACK SVD (eps |A|) for the short ones -- whose
             // directions are rounding noise of the products that made A and would never settle under the relative test
-            if (g2 > tol2 * fmax(al, be) * fmax(fmin(al, be), 1e-3 * frob)) {
+            const double scale2 = fmax(al, be) * fmax(fmin(al, be), 1e-3 * frob);
+            if (g2 > tol2 * scale2) {
+              if (gl == 0) atomicMax(&sh->worst, (unsigned long long)__double_as_longlong(g2 / scale2));
               const double iga = rsqrt(g2);                  // 1 / |<a1, a2>|
               const double zeta = 0.5 * (be - al) * iga;
               const double t = copysign(1.0, zeta) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
@@ -143,8 +160,8 @@ __device__ void jacobi_orth(cd* A, const long rs, const long cs, const int p, co
                 a1[i * rs] = cfma(s1, y, cd{c * x.x, c * x.y});
                 a2[i * rs] = cfma(s2, x, cd{c * y.x, c * y.y});
               }
-              cd* v1 = V + c1 * vcs;
-              cd* v2 = V + c2 * vcs;
+              P v1 = V + c1 * vcs;
+              P v2 = V + c2 * vcs;
               for (int i = gl; i < q; i += GL) {
                 const cd x = v1[i * vrs], y = v2[i * vrs];
                 v1[i * vrs] = cfma(s1, y, cd{c * x.x, c * x.y});
@@ -161,10 +178,17 @@ __device__ void jacobi_orth(cd* A, const long rs, const long cs, const int p, co
       if (!f) break;
     }
     if (tid == 0) {
-      if (sweep == MAX_SWEEPS) atomicOr(error, ERR_SWEEPS), atomicAdd(error + 4, 1);
+      // out of sweeps: a residue below 1e-10 (relative) is harmless for the truncation and the canonical form (it
+      // perturbs singular values by 1e-20); anything larger is reported
+      if (sweep == MAX_SWEEPS) {
+        atomicAdd(error + 4, 1);
+        if (__longlong_as_double((long long)sh->worst) > 1e-20) atomicOr(error, ERR_SWEEPS);
+      }
       atomicAdd(error + 1, 1);              // statistics: factorisations, sweeps, most sweeps of one factorisation
       atomicAdd(error + 2, min(sweep + 1, MAX_SWEEPS));
       atomicMax(error + 3, min(sweep + 1, MAX_SWEEPS));
+      atomicAdd(reinterpret_cast<unsigned long long*>(error + 8), (unsigned long long)(wall_clock64() - t_begin));  // 100 MHz ticks in sweeps
+      atomicAdd(reinterpret_cast<unsigned long long*>(error + 10), (unsigned long long)(min(sweep + 1, MAX_SWEEPS) * nr));  // steps
     }
   }
   for (int jc = grp; jc < q; jc += NG) {
@@ -173,8 +197,7 @@ __device__ void jacobi_orth(cd* A, const long rs, const long cs, const int p, co
       const cd x = A[i * rs + jc * cs];
       al += x.x * x.x + x.y * x.y;
     }
-#pragma unroll
-    for (int m = GL / 2; m > 0; m >>= 1) al += __shfl_xor(al, m, GL);
+    al = group_sum(al);
     sig[jc] = sqrt(al);
   }
   __syncthreads();
@@ -196,6 +219,7 @@ __device__ void jacobi_orth(cd* A, const long rs, const long cs, const int p, co
 __device__ void jacobi_auto(cd* A, const long rs, const long cs, const int p, const int q, cd* V, double* sig, int* ord, WgShared* sh,
                             int* error, cd* lds, const int lds_elems, cd* scratch) {
   const int ld = q | 1;
+  if (threadIdx.x == 0) atomicAdd(error + (((long)(p + q) * ld <= lds_elems) ? 5 : 6), 1);  // statistics: LDS-resident / L2-resident
   if ((long)(p + q) * ld <= lds_elems) {
     cd* LA = lds;
     cd* LV = lds + (long)p * ld;
@@ -208,8 +232,7 @@ __device__ void jacobi_auto(cd* A, const long rs, const long cs, const int p, co
           const cd x = A[i * rs + jc * cs];
           al += x.x * x.x + x.y * x.y;
         }
-#pragma unroll
-        for (int m = GL / 2; m > 0; m >>= 1) al += __shfl_xor(al, m, GL);
+        al = group_sum(al);
         sig[jc] = al;
       }
       __syncthreads();
@@ -233,14 +256,14 @@ __device__ void jacobi_auto(cd* A, const long rs, const long cs, const int p, co
       }
       __syncthreads();
     }
-    jacobi_orth(LA, ld, 1, p, q, LV, ld, 1, sig, ord, sh, error, false);
+    jacobi_orth((lds_cd_ptr)LA, ld, 1, p, q, (lds_cd_ptr)LV, ld, 1, sig, ord, sh, error, false);
 #else
     for (int e = threadIdx.x; e < p * q; e += BT) {
       const int i = e / q, jc = e - i * q;
       LA[i * ld + jc] = A[i * rs + jc * cs];
     }
     __syncthreads();
-    jacobi_orth(LA, ld, 1, p, q, LV, ld, 1, sig, ord, sh, error);
+    jacobi_orth((lds_cd_ptr)LA, ld, 1, p, q, (lds_cd_ptr)LV, ld, 1, sig, ord, sh, error);
 #endif
     for (int e = threadIdx.x; e < p * q; e += BT) {
       const int i = e / q, jc = e - i * q;
@@ -288,15 +311,57 @@ __device__ void jacobi_auto(cd* A, const long rs, const long cs, const int p, co
 }
 
 // C[M x N] (row-major, ld N) = sum_k A(i, k) B(k, j); A(i, k) at A[i * ars + k * acs], B(k, j) at B[k * brs + j * bcs]
+// Register-blocked: a thread owns a 4 x 4 block of C (16 independent accumulators, 8 operand loads per 16 products; the plain
+// one-output-per-thread loop was latency-bound and took 85 % of the build time at bonds of 100).  Optional operand maps:
+// row i of A is taken from source row amap[i] (conjugated if CONJA) and the result row scaled by rscale[amap[i]]; likewise
+// column j of B from bmap[j] (conjugated if CONJB), result column scaled by cscale[bmap[j]] -- that is how the centre moves
+// multiply by R = diag(s) V^H with the columns of V in sorted order.
+template <bool CONJA, bool CONJB>
 __device__ void wg_gemm(cd* __restrict__ C, const int M, const int N, const int K, const cd* __restrict__ A, const long ars, const long acs,
-                        const cd* __restrict__ B, const long brs, const long bcs) {
-  for (int e = threadIdx.x; e < M * N; e += BT) {
-    const int i = e / N, jn = e - i * N;
-    cd acc = cd{0.0, 0.0};
-    const cd* pa = A + i * ars;
-    const cd* pb = B + jn * bcs;
-    for (int k = 0; k < K; ++k) acc = cfma(pa[k * acs], pb[k * brs], acc);
-    C[e] = acc;
+                        const cd* __restrict__ B, const long brs, const long bcs, const int* amap = nullptr, const double* rscale = nullptr,
+                        const int* bmap = nullptr, const double* cscale = nullptr) {
+  const int tn = (N + 3) / 4, tiles = ((M + 3) / 4) * tn;
+  for (int t = threadIdx.x; t < tiles; t += BT) {
+    const int ti = t / tn, tj = t - ti * tn;
+    const cd* pa[4];
+    const cd* pb[4];
+    double ra[4], cb[4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      const int i = min(4 * ti + a, M - 1), si = amap ? amap[i] : i;
+      pa[a] = A + si * ars;
+      ra[a] = rscale ? rscale[si] : 1.0;
+      const int jn = min(4 * tj + a, N - 1), sj = bmap ? bmap[jn] : jn;
+      pb[a] = B + sj * bcs;
+      cb[a] = cscale ? cscale[sj] : 1.0;
+    }
+    cd acc[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int b = 0; b < 4; ++b) acc[a][b] = cd{0.0, 0.0};
+    for (int k = 0; k < K; ++k) {
+      cd av[4], bv[4];
+#pragma unroll
+      for (int a = 0; a < 4; ++a) {
+        av[a] = pa[a][k * acs];
+        bv[a] = pb[a][k * brs];
+        if (CONJA) av[a].y = -av[a].y;
+        if (CONJB) bv[a].y = -bv[a].y;
+      }
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = cfma(av[a], bv[b], acc[a][b]);
+    }
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int b = 0; b < 4; ++b)
+        if (4 * ti + a < M && 4 * tj + b < N) {
+          const double f = ra[a] * cb[b];
+          C[(long)(4 * ti + a) * N + 4 * tj + b] = cd{acc[a][b].x * f, acc[a][b].y * f};
+        }
   }
   __syncthreads();
 }
@@ -349,12 +414,16 @@ __global__ __launch_bounds__(BT) void qk_build_kernel(const BuildArgs g) {
   cd* const VV = TH + wslot;
   cd* const TMP = VV + wslot;
   const double sqrt_half = 0.7071067811865476;
+  const long long wg_begin = wall_clock64();
   for (;;) {
     if (tid == 0) sh.state = (int)atomicAdd(g.counter, 1ull);
     __syncthreads();
     const int st = sh.state;
     __syncthreads();
-    if (st >= g.n_states) break;
+    if (st >= g.n_states) {
+      if (tid == 0) atomicAdd(reinterpret_cast<unsigned long long*>(g.error + 12), (unsigned long long)(wall_clock64() - wg_begin));  // busy ticks
+      break;
+    }
     for (int k = tid; k <= n; k += BT) dims[k] = 1;
     for (int k = tid; k < n; k += BT) {
       sites[k * slot] = cd{1.0, 0.0};
@@ -412,18 +481,8 @@ __global__ __launch_bounds__(BT) void qk_build_kernel(const BuildArgs g) {
           TMP[e] = (s > 0) ? cd{w.x / s, w.y / s} : cd{0.0, 0.0};
         }
         // R[jj][c] = s_jj conj(V[c][ord jj]); u'[jj][x] = sum_c R[jj][c] u[c][x]
-        for (int e = tid; e < k * 2 * r2; e += BT) {
-          const int jj = e / (2 * r2), x = e - jj * (2 * r2);
-          const int cj = ord[jj];
-          cd acc = cd{0.0, 0.0};
-          for (int c = 0; c < r; ++c) {
-            const cd v = VV[c * r + cj];
-            acc = cfma(cd{v.x, -v.y}, u[c * (2 * r2) + x], acc);
-          }
-          const double s = sig[cj];
-          TH[e] = cd{acc.x * s, acc.y * s};
-        }
         __syncthreads();
+        wg_gemm<true, false>(TH, k, 2 * r2, r, VV, 1, r, u, 2 * r2, 1, ord, sig);  // A(jj, c) = conj(V[c][ord jj]), row scale s
         wg_copy(t, TMP, (long)m * k);
         wg_copy(u, TH, (long)k * 2 * r2);
         if (tid == 0) dims[centre + 1] = k;
@@ -453,18 +512,8 @@ __global__ __launch_bounds__(BT) void qk_build_kernel(const BuildArgs g) {
           TMP[e] = (s > 0) ? cd{x.x / s, x.y / s} : cd{0.0, 0.0};
         }
         // t^T = Q R with R[jj][a] = s_jj conj(V[a][ord jj]);  d'[i][jj] = sum_a d[i][a] R[jj][a]
-        for (int e = tid; e < 2 * l0 * k; e += BT) {
-          const int row = e / k, jj = e - row * k;
-          const int cj = ord[jj];
-          cd acc = cd{0.0, 0.0};
-          for (int a = 0; a < l; ++a) {
-            const cd v = VV[a * l + cj];
-            acc = cfma(cd{v.x, -v.y}, d[row * l + a], acc);
-          }
-          const double s = sig[cj];
-          TH[e] = cd{acc.x * s, acc.y * s};
-        }
         __syncthreads();
+        wg_gemm<false, true>(TH, 2 * l0, k, l, d, l, 1, VV, l, 1, nullptr, nullptr, ord, sig);  // B(a, jj) = conj(V[a][ord jj]), column scale s
         wg_copy(t, TMP, (long)k * w);
         wg_copy(d, TH, (long)2 * l0 * k);
         if (tid == 0) dims[centre] = k;
@@ -475,7 +524,7 @@ __global__ __launch_bounds__(BT) void qk_build_kernel(const BuildArgs g) {
       cd* a1 = sites + (q + 1) * slot;
       const int l = dims[q], mid = dims[q + 1], r = dims[q + 2];
       const int m = 2 * l, nn = 2 * r;
-      wg_gemm(TH, m, nn, mid, a0, mid, 1, a1, nn, 1);  // theta[(a,p)][(p',c)]
+      wg_gemm<false, false>(TH, m, nn, mid, a0, mid, 1, a1, nn, 1);  // theta[(a,p)][(p',c)]
       {
         const double th = 0.5 * M_PI * alpha[i];
         const double cs = cos(th), sn = sin(th);
@@ -681,14 +730,14 @@ extern "C" int qk_build_mps(qk_ctx* c, int32_t n_states, int32_t n_qubits, int32
   BUILD_TRY(hipMalloc(&d_dims, (size_t)n_states * (n_qubits + 1) * sizeof(int32_t)));
   BUILD_TRY(hipMalloc(&d_offs, (size_t)n_states * sizeof(long long)));
   BUILD_TRY(hipMalloc(&d_ctr, 2 * sizeof(unsigned long long)));
-  BUILD_TRY(hipMalloc(&d_err, 8 * sizeof(int)));
+  BUILD_TRY(hipMalloc(&d_err, 16 * sizeof(int)));
   if (n_ops > 0) {
     BUILD_TRY(hipMemcpyAsync(d_op, op, n_ops, hipMemcpyHostToDevice, c->stream));
     BUILD_TRY(hipMemcpyAsync(d_q0, q0, (size_t)n_ops * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
     BUILD_TRY(hipMemcpyAsync(d_alpha, alpha, (size_t)n_states * n_ops * sizeof(double), hipMemcpyHostToDevice, c->stream));
   }
   BUILD_TRY(hipMemsetAsync(d_ctr, 0, 2 * sizeof(unsigned long long), c->stream));
-  BUILD_TRY(hipMemsetAsync(d_err, 0, 8 * sizeof(int), c->stream));
+  BUILD_TRY(hipMemsetAsync(d_err, 0, 16 * sizeof(int), c->stream));
   BuildArgs a;
   a.n_states = n_states, a.n_qubits = n_qubits, a.n_ops = n_ops, a.cap = cap;
   a.op = d_op, a.q0 = d_q0, a.alpha = d_alpha;
@@ -706,7 +755,7 @@ extern "C" int qk_build_mps(qk_ctx* c, int32_t n_states, int32_t n_qubits, int32
   b->fidelity.resize(n_states);
   b->offsets.resize(n_states);
   std::vector<long long> offs(n_states);
-  int errv[8] = {0};
+  int errv[16] = {0};
   unsigned long long ctr[2] = {0, 0};
   hipError_t e = hipStreamSynchronize(c->stream);
   if (e == hipSuccess) e = hipMemcpy(b->dims.data(), d_dims, b->dims.size() * sizeof(int32_t), hipMemcpyDeviceToHost);
@@ -724,8 +773,17 @@ extern "C" int qk_build_mps(qk_ctx* c, int32_t n_states, int32_t n_qubits, int32
   }
   const int err = errv[0];
   if (std::getenv("QK_BUILD_DEBUG"))
-    std::fprintf(stderr, "[qk_build_mps] %d states, grid %lld, %.1f ms; Jacobi: %d factorisations, %.2f sweeps on average, %d at most, %d unconverged; error bits %d\n",
-                 n_states, grid, ms, errv[1], errv[1] ? (double)errv[2] / errv[1] : 0.0, errv[3], errv[4], err);
+    std::fprintf(stderr, "[qk_build_mps] %d states, grid %lld, %.1f ms; Jacobi: %d factorisations, %.2f sweeps on average, %d at most, %d unconverged, %d in LDS / %d from L2; error bits %d\n",
+                 n_states, grid, ms, errv[1], errv[1] ? (double)errv[2] / errv[1] : 0.0, errv[3], errv[4], errv[5], errv[6], err);
+  if (std::getenv("QK_BUILD_DEBUG")) {
+    unsigned long long ticks = 0, steps = 0;
+    std::memcpy(&ticks, errv + 8, 8), std::memcpy(&steps, errv + 10, 8);
+    unsigned long long busy = 0;
+    std::memcpy(&busy, errv + 12, 8);
+    std::fprintf(stderr, "[qk_build_mps] workgroups busy %.1f %% of the launch (%.3f s of workgroup time per state); sweeps are %.1f %% of the busy time (%.2f us per step, %llu steps)\n",
+                 100.0 * (double)busy / 1e8 / ((double)grid * ms / 1e3), (double)busy / 1e8 / n_states, 100.0 * (double)ticks / (double)std::max(1ull, busy),
+                 steps ? (double)ticks / 100.0 / (double)steps : 0.0, steps);
+  }
   if (err) {
     (void)hipFree(heap);
     delete b;
@@ -831,8 +889,8 @@ extern "C" int qk_debug_jacobi(qk_ctx* c, int32_t p, int32_t q, double* a_inout,
   HIP_TRY(hipMalloc(&dV, (size_t)q * q * sizeof(cd)));
   HIP_TRY(hipMalloc(&dS, (size_t)q * sizeof(double)));
   HIP_TRY(hipMalloc(&dO, (size_t)q * sizeof(int)));
-  HIP_TRY(hipMalloc(&dE, 8 * sizeof(int)));
-  HIP_TRY(hipMemset(dE, 0, 8 * sizeof(int)));
+  HIP_TRY(hipMalloc(&dE, 16 * sizeof(int)));
+  HIP_TRY(hipMemset(dE, 0, 16 * sizeof(int)));
   HIP_TRY(hipMemcpy(dA, a_inout, (size_t)p * q * sizeof(cd), hipMemcpyHostToDevice));
   qk_jacobi_kernel<<<dim3(1), dim3(BT), (size_t)q * (sizeof(double) + sizeof(int)) + 16, c->stream>>>(dA, p, q, dV, dS, dO, dE);
   HIP_TRY(hipGetLastError());
