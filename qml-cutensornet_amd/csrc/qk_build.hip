@@ -87,7 +87,9 @@ struct WgShared {
 // One-sided Jacobi.  A is p x q, element (i, j) at A[i * rs + j * cs].  On return A <- A V with mutually orthogonal columns and V
 // (q x q, element (i, c) at V[i * vrs + c * vcs]) holds the accumulated unitary; sig[j] = |column j|, ord = column indices by decreasing sig.
 typedef __attribute__((address_space(3))) cd* lds_cd_ptr;  // LDS-typed: ds_read/ds_write instead of flat accesses
-template <typename P>  // P = cd* (L2-resident workspace) or lds_cd_ptr
+// R > 0: every lane keeps its rows of the two columns in registers (p, q <= R * GL): all loads of a step are issued at
+// once and the rotation does not read the columns a second time; R = 0 is the general loop.
+template <typename P, int R = 0>  // P = cd* (L2-resident workspace) or lds_cd_ptr
 __device__ void jacobi_orth(P A, const long rs, const long cs, const int p, const int q, P V, const int vrs, const int vcs,
                             double* sig, int* ord, WgShared* sh, int* error, const bool init_v = true) {
   const int tid = threadIdx.x, gl = tid % GL;
@@ -133,12 +135,31 @@ __device__ void jacobi_orth(P A, const long rs, const long cs, const int p, cons
             P a1 = A + c1 * cs;
             P a2 = A + c2 * cs;
             double al = 0, be = 0, gr = 0, gi = 0;
-            for (int i = gl; i < p; i += GL) {
-              const cd x = a1[i * rs], y = a2[i * rs];
-              al += x.x * x.x + x.y * x.y;
-              be += y.x * y.x + y.y * y.y;
-              gr += x.x * y.x + x.y * y.y;  // conj(x) * y
-              gi += x.x * y.y - x.y * y.x;
+            cd xa[R > 0 ? R : 1], ya[R > 0 ? R : 1];
+            if constexpr (R > 0) {
+#pragma unroll
+              for (int u = 0; u < R; ++u) {
+                const int i = gl + u * GL;
+                const bool in = i < p;
+                xa[u] = in ? a1[i * rs] : cd{0.0, 0.0};
+                ya[u] = in ? a2[i * rs] : cd{0.0, 0.0};
+              }
+#pragma unroll
+              for (int u = 0; u < R; ++u) {
+                const cd x = xa[u], y = ya[u];
+                al += x.x * x.x + x.y * x.y;
+                be += y.x * y.x + y.y * y.y;
+                gr += x.x * y.x + x.y * y.y;
+                gi += x.x * y.y - x.y * y.x;
+              }
+            } else {
+              for (int i = gl; i < p; i += GL) {
+                const cd x = a1[i * rs], y = a2[i * rs];
+                al += x.x * x.x + x.y * x.y;
+                be += y.x * y.x + y.y * y.y;
+                gr += x.x * y.x + x.y * y.y;  // conj(x) * y
+                gi += x.x * y.y - x.y * y.x;
+              }
             }
             al = group_sum(al), be = group_sum(be), gr = group_sum(gr), gi = group_sum(gi);
             const double g2 = gr * gr + gi * gi;
@@ -148,6 +169,18 @@ __device__ void jacobi_orth(P A, const long rs, const long cs, const int p, cons
             const double scale2 = fmax(al, be) * fmax(fmin(al, be), 1e-3 * frob);
             if (g2 > tol2 * scale2) {
               if (gl == 0) atomicMax(&sh->worst, (unsigned long long)__double_as_longlong(g2 / scale2));
+              P v1 = V + c1 * vcs;
+              P v2 = V + c2 * vcs;
+              cd xv[R > 0 ? R : 1], yv[R > 0 ? R : 1];
+              if constexpr (R > 0) {  // the V rows travel while the rotation is being worked out
+#pragma unroll
+                for (int u = 0; u < R; ++u) {
+                  const int i = gl + u * GL;
+                  const bool in = i < q;
+                  xv[u] = in ? v1[i * vrs] : cd{0.0, 0.0};
+                  yv[u] = in ? v2[i * vrs] : cd{0.0, 0.0};
+                }
+              }
               const double iga = rsqrt(g2);                  // 1 / |<a1, a2>|
               const double zeta = 0.5 * (be - al) * iga;
               const double t = copysign(1.0, zeta) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
@@ -155,17 +188,34 @@ __device__ void jacobi_orth(P A, const long rs, const long cs, const int p, cons
               const double phr = gr * iga, phi = gi * iga;  // e^{i phi}
               const cd s1 = cd{-s * phr, s * phi};        // -s conj(ph)
               const cd s2 = cd{s * phr, s * phi};         //  s ph
-              for (int i = gl; i < p; i += GL) {
-                const cd x = a1[i * rs], y = a2[i * rs];
-                a1[i * rs] = cfma(s1, y, cd{c * x.x, c * x.y});
-                a2[i * rs] = cfma(s2, x, cd{c * y.x, c * y.y});
-              }
-              P v1 = V + c1 * vcs;
-              P v2 = V + c2 * vcs;
-              for (int i = gl; i < q; i += GL) {
-                const cd x = v1[i * vrs], y = v2[i * vrs];
-                v1[i * vrs] = cfma(s1, y, cd{c * x.x, c * x.y});
-                v2[i * vrs] = cfma(s2, x, cd{c * y.x, c * y.y});
+              if constexpr (R > 0) {
+#pragma unroll
+                for (int u = 0; u < R; ++u) {
+                  const int i = gl + u * GL;
+                  if (i < p) {
+                    a1[i * rs] = cfma(s1, ya[u], cd{c * xa[u].x, c * xa[u].y});
+                    a2[i * rs] = cfma(s2, xa[u], cd{c * ya[u].x, c * ya[u].y});
+                  }
+                }
+#pragma unroll
+                for (int u = 0; u < R; ++u) {
+                  const int i = gl + u * GL;
+                  if (i < q) {
+                    v1[i * vrs] = cfma(s1, yv[u], cd{c * xv[u].x, c * xv[u].y});
+                    v2[i * vrs] = cfma(s2, xv[u], cd{c * yv[u].x, c * yv[u].y});
+                  }
+                }
+              } else {
+                for (int i = gl; i < p; i += GL) {
+                  const cd x = a1[i * rs], y = a2[i * rs];
+                  a1[i * rs] = cfma(s1, y, cd{c * x.x, c * x.y});
+                  a2[i * rs] = cfma(s2, x, cd{c * y.x, c * y.y});
+                }
+                for (int i = gl; i < q; i += GL) {
+                  const cd x = v1[i * vrs], y = v2[i * vrs];
+                  v1[i * vrs] = cfma(s1, y, cd{c * x.x, c * x.y});
+                  v2[i * vrs] = cfma(s2, x, cd{c * y.x, c * y.y});
+                }
               }
               sh->flag = 1;
             }
@@ -256,7 +306,17 @@ __device__ void jacobi_auto(cd* A, const long rs, const long cs, const int p, co
       }
       __syncthreads();
     }
-    jacobi_orth((lds_cd_ptr)LA, ld, 1, p, q, (lds_cd_ptr)LV, ld, 1, sig, ord, sh, error, false);
+    {
+      const lds_cd_ptr la = (lds_cd_ptr)LA, lv = (lds_cd_ptr)LV;
+      const int rows = (max(p, q) + GL - 1) / GL;  // rows of a column per lane
+#ifndef QK_BUILD_NO_REGS
+      if (rows <= 2) jacobi_orth<lds_cd_ptr, 2>(la, ld, 1, p, q, lv, ld, 1, sig, ord, sh, error, false);
+      else if (rows <= 4) jacobi_orth<lds_cd_ptr, 4>(la, ld, 1, p, q, lv, ld, 1, sig, ord, sh, error, false);
+      else if (rows <= 8) jacobi_orth<lds_cd_ptr, 8>(la, ld, 1, p, q, lv, ld, 1, sig, ord, sh, error, false);
+      else
+#endif
+        jacobi_orth<lds_cd_ptr, 0>(la, ld, 1, p, q, lv, ld, 1, sig, ord, sh, error, false);
+    }
 #else
     for (int e = threadIdx.x; e < p * q; e += BT) {
       const int i = e / q, jc = e - i * q;
@@ -400,7 +460,7 @@ __device__ void wg_kept(const double* sig, const int* ord, const int n, const do
   __syncthreads();
 }
 
-__global__ __launch_bounds__(BT) void qk_build_kernel(const BuildArgs g) {
+__global__ __launch_bounds__(BT, 2) void qk_build_kernel(const BuildArgs g) {
   extern __shared__ double sh_raw[];
   const int n = g.n_qubits, cap = g.cap, tid = threadIdx.x;
   double* sig = sh_raw;                                   // [2 cap]
