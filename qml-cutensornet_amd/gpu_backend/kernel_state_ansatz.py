@@ -51,16 +51,25 @@ def _simulate_share(ansatz, points, rank, n_procs, fidelity, is_root, label):
     per_rank = -(-len(points) // n_procs)
     lo = min(len(points), rank * per_rank)
     hi = min(len(points), lo + per_rank)
-    if os.environ.get("QK_BUILDER", "host") == "device" and hi > lo:
+    which = os.environ.get("QK_BUILDER", "host")
+    if which in ("device", "auto") and hi > lo:
         # the rank's whole share in ONE launch of the device builder (csrc/qk_build.hip): what the reference does with
         # simulate(libhandle, ...) on the rank's GPU (ref :221,:263).  Pays off at the small bonds of the reference's own
-        # runs (profiles/r01/device_builder_bench.txt); the host builder stays the default.
+        # runs (profiles/r01/device_builder_bench.txt); the host builder stays the default.  "auto" tries the device with
+        # bonds capped at 64 (the regime where it wins) and hands the share to the host builder if a state outgrows that.
         t0 = time.perf_counter()
-        states, _ = _engine.default_context().build_mps([ansatz.circuit_for_data(points[k, :]) for k in range(lo, hi)], fidelity,
-                                                        max_bond=int(os.environ.get("QK_BUILDER_MAX_BOND", "256")))
-        dt = (time.perf_counter() - t0) / (hi - lo)
-        _say(is_root, f"{label}: 100%")
-        return lo, states, [dt] * (hi - lo)
+        cap = int(os.environ.get("QK_BUILDER_MAX_BOND", "256" if which == "device" else "64"))
+        try:
+            states, _ = _engine.default_context().build_mps([ansatz.circuit_for_data(points[k, :]) for k in range(lo, hi)], fidelity, max_bond=cap)
+        except _engine.QkError as exc:
+            if which == "device":
+                raise
+            _say(is_root, f"{label}: device builder gave up ({exc}); building on the host")
+            states = None
+        if states is not None:
+            dt = (time.perf_counter() - t0) / (hi - lo)
+            _say(is_root, f"{label}: 100%")
+            return lo, states, [dt] * (hi - lo)
     states, secs = [], []
     tick = max(1, per_rank // 10)
     for k in range(lo, hi):

@@ -139,3 +139,23 @@ def test_built_states_stay_on_the_device(gpu_ctx):
     K_sv = R.gram_statevector(X, None, reps, 0.7, Q.entanglement_graph(n, d))
     assert np.abs(gpu_ctx.gram(dset) - K_sv).max() < 1e-8
     dset.close()
+
+
+def test_auto_builder_falls_back_to_the_host(built, monkeypatch, capsys):
+    """QK_BUILDER=auto: the device builder with bonds capped (here at 4, so that it must give up), then the host builder."""
+    import qml_cutensornet_amd as Q
+    from qml_cutensornet_amd.dist import SingleComm
+    from qml_cutensornet_amd.gpu_backend.kernel_state_ansatz import KernelStateAnsatz, build_kernel_matrix
+
+    g = golden("deep_10q_r3_d3.npz")
+    n, reps, gamma = int(g["n"]), int(g["reps"]), float(g["gamma"])
+    ans = KernelStateAnsatz(num_qubits=n, reps=reps, gamma=gamma, entanglement_map=Q.entanglement_graph(n, int(g["d"])), hadamard_init=True)
+    monkeypatch.setenv("QK_BUILDER", "auto")
+    monkeypatch.setenv("QK_BUILDER_MAX_BOND", "4")
+    K = build_kernel_matrix(SingleComm(), ans, X=g["X_train"], truncation_error=1e-16)
+    assert "building on the host" in capsys.readouterr().out
+    assert np.abs(K - g["K_train"]).max() < 1e-8
+    monkeypatch.setenv("QK_BUILDER_MAX_BOND", "64")
+    K2 = build_kernel_matrix(SingleComm(), ans, X=g["X_train"], truncation_error=1e-16)
+    assert "building on the host" not in capsys.readouterr().out
+    assert np.abs(K2 - g["K_train"]).max() < 1e-8
