@@ -117,6 +117,7 @@ __device__ void jacobi_orth(P A, const long rs, const long cs, const int p, cons
   if (q >= 2) {
     const int qe = q + (q & 1), half = qe / 2, nr = qe - 1;
     int sweep = 0;
+    bool done = false;
     const long long t_begin = wall_clock64();
     for (; sweep < MAX_SWEEPS; ++sweep) {
       if (tid == 0) sh->flag = 0, sh->worst = 0ull;
@@ -224,21 +225,28 @@ __device__ void jacobi_orth(P A, const long rs, const long cs, const int p, cons
         __syncthreads();
       }
       const int f = sh->flag;
+      const double worst = __longlong_as_double((long long)sh->worst);
       __syncthreads();
-      if (!f) break;
+      // done when nothing was rotated -- or only pairs that were already orthogonal to 1e-10: a rotation leaves a residue
+      // of the order of the square of what it removed, far below the test, so the checking sweep can be skipped
+      if (!f || worst <= 1e-20) {
+        done = true;
+        ++sweep;
+        break;
+      }
     }
     if (tid == 0) {
       // out of sweeps: a residue below 1e-10 (relative) is harmless for the truncation and the canonical form (it
       // perturbs singular values by 1e-20); anything larger is reported
-      if (sweep == MAX_SWEEPS) {
+      if (!done) {
         atomicAdd(error + 4, 1);
         if (__longlong_as_double((long long)sh->worst) > 1e-20) atomicOr(error, ERR_SWEEPS);
       }
       atomicAdd(error + 1, 1);              // statistics: factorisations, sweeps, most sweeps of one factorisation
-      atomicAdd(error + 2, min(sweep + 1, MAX_SWEEPS));
-      atomicMax(error + 3, min(sweep + 1, MAX_SWEEPS));
+      atomicAdd(error + 2, min(sweep, MAX_SWEEPS));
+      atomicMax(error + 3, min(sweep, MAX_SWEEPS));
       atomicAdd(reinterpret_cast<unsigned long long*>(error + 8), (unsigned long long)(wall_clock64() - t_begin));  // 100 MHz ticks in sweeps
-      atomicAdd(reinterpret_cast<unsigned long long*>(error + 10), (unsigned long long)(min(sweep + 1, MAX_SWEEPS) * nr));  // steps
+      atomicAdd(reinterpret_cast<unsigned long long*>(error + 10), (unsigned long long)(min(sweep, MAX_SWEEPS) * nr));  // steps
     }
   }
   for (int jc = grp; jc < q; jc += NG) {
