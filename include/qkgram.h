@@ -185,8 +185,11 @@ int qk_selftest_mfma(qk_ctx* ctx);
  * (QK_EINVAL if a state outgrows it).  The result stays on the device until downloaded: per state and site a
  * complex128 tensor [chi_l][2][chi_r] row-major, sites back to back, state s at offsets[s] (complex elements).    */
 typedef struct qk_built qk_built;
+#define QK_BUILD_PARTIAL 1u /* a state that outgrows max_bond is dropped (its fidelity reads -1, it has no tensors: build it
+                             * elsewhere) instead of failing the call; its workgroup stops at the offending gate        */
 int qk_build_mps(qk_ctx* ctx, int32_t n_states, int32_t n_qubits, int32_t n_ops, const int8_t* op, const int32_t* q0,
-                 const double* alpha, double trunc_budget, double value_of_zero, int32_t max_bond, qk_built** out);
+                 const double* alpha, double trunc_budget, double value_of_zero, int32_t max_bond, uint32_t flags,
+                 qk_built** out);
 /* dims[n_states][n_qubits+1], fidelity[n_states], offsets[n_states], total complex elements, kernel time; any may be NULL */
 int qk_built_info(const qk_built* built, int32_t* dims, double* fidelity, int64_t* offsets, int64_t* total_complex,
                   double* kernel_ms);

@@ -74,6 +74,7 @@ struct BuildArgs {
   int* error;     // [0] error bits, [1..4] Jacobi statistics: factorisations, sweeps, most sweeps, unconverged
   int jl_offset;  // doubles from the start of the dynamic LDS to the Jacobi working set
   int jl_elems;   // complex elements it holds
+  int partial;    // a state that outgrows cap is dropped (fidelity -1) instead of failing the call
 };
 
 // Shared scalars of a workgroup (one instance in LDS).
@@ -501,7 +502,8 @@ __global__ __launch_bounds__(BT, 2) void qk_build_kernel(const BuildArgs g) {
     const double* alpha = g.alpha + (long)st * g.n_ops;
     double fidelity = 1.0;
     int centre = 0;
-    for (int i = 0; i < g.n_ops; ++i) {
+    bool outgrown = false;
+    for (int i = 0; i < g.n_ops && !outgrown; ++i) {
       const int o = g.op[i], q = g.q0[i];
       if (q < 0 || q >= n || (o >= OP_XX && q + 1 >= n) || o < 0 || o > OP_SWAP) {
         if (tid == 0) atomicOr(g.error, ERR_GATE);
@@ -625,7 +627,8 @@ __global__ __launch_bounds__(BT, 2) void qk_build_kernel(const BuildArgs g) {
       fidelity *= sh.frac;
       const double nrm = sh.nrm;
       if (keep > cap) {
-        if (tid == 0) atomicOr(g.error, ERR_BOND);
+        outgrown = true;  // the program of this state stops after this gate
+        if (tid == 0 && !g.partial) atomicOr(g.error, ERR_BOND);
         keep = cap;
       }
       int nxt = q;
@@ -673,7 +676,9 @@ __global__ __launch_bounds__(BT, 2) void qk_build_kernel(const BuildArgs g) {
     // ---- pack the finished state into the heap
     if (tid == 0) {
       unsigned long long total = 0;
-      for (int k = 0; k < n; ++k) total += 2ull * dims[k] * dims[k + 1];
+      if (outgrown) fidelity = -1.0;  // marks a dropped state; it gets no tensors
+      else
+        for (int k = 0; k < n; ++k) total += 2ull * dims[k] * dims[k + 1];
       const unsigned long long off = atomicAdd(g.heap_top, total);
       sh.off = off;
       sh.flag = (off + total <= g.heap_cap);
@@ -683,7 +688,7 @@ __global__ __launch_bounds__(BT, 2) void qk_build_kernel(const BuildArgs g) {
     }
     __syncthreads();
     for (int k = tid; k <= n; k += BT) g.dims_out[(long)st * (n + 1) + k] = dims[k];
-    if (sh.flag) {
+    if (sh.flag && !outgrown) {
       unsigned long long pos = sh.off;
       for (int k = 0; k < n; ++k) {
         const long cnt = 2L * dims[k] * dims[k + 1];
@@ -741,7 +746,7 @@ struct qk_built {
 };
 
 extern "C" int qk_build_mps(qk_ctx* c, int32_t n_states, int32_t n_qubits, int32_t n_ops, const int8_t* op, const int32_t* q0,
-                            const double* alpha, double trunc_budget, double value_of_zero, int32_t max_bond, qk_built** out) {
+                            const double* alpha, double trunc_budget, double value_of_zero, int32_t max_bond, uint32_t flags, qk_built** out) {
   if (!c || !op || !q0 || !alpha || !out) return qk_fail(QK_EINVAL, "qk_build_mps: null argument");
   if (n_states <= 0 || n_qubits <= 0 || n_ops < 0) return qk_fail(QK_EINVAL, "qk_build_mps: empty problem (%d states, %d qubits, %d gates)", n_states, n_qubits, n_ops);
   if (max_bond < 2 || max_bond > 1024) return qk_fail(QK_EINVAL, "qk_build_mps: max_bond %d outside 2..1024", max_bond);
@@ -813,6 +818,7 @@ extern "C" int qk_build_mps(qk_ctx* c, int32_t n_states, int32_t n_qubits, int32
   a.arena = arena, a.work = work, a.heap = heap, a.heap_cap = heap_cap, a.heap_top = d_ctr + 1;
   a.dims_out = d_dims, a.fid_out = d_fid, a.offs_out = d_offs, a.counter = d_ctr, a.error = d_err;
   a.jl_offset = (int)(lds_meta / sizeof(double)), a.jl_elems = jl_elems;
+  a.partial = (flags & QK_BUILD_PARTIAL) ? 1 : 0;
   BUILD_TRY(hipEventRecord(c->ev0, c->stream));
   qk_build_kernel<<<dim3((unsigned)grid), dim3(BT), lds, c->stream>>>(a);
   BUILD_TRY(hipGetLastError());
@@ -888,6 +894,8 @@ extern "C" int qk_built_download(const qk_built* b, double* host) {
 extern "C" int qk_mps_set_from_built(qk_ctx* c, const qk_built* b, qk_mps_set** out) {
   if (!c || !b || !out) return qk_fail(QK_EINVAL, "qk_mps_set_from_built: null argument");
   if (b->ctx != c) return qk_fail(QK_EINVAL, "qk_mps_set_from_built: the states were built in another context");
+  for (int s = 0; s < b->n_states; ++s)
+    if (b->fidelity[s] < 0) return qk_fail(QK_EINVAL, "qk_mps_set_from_built: state %d outgrew max_bond and was dropped (QK_BUILD_PARTIAL)", s);
   HIP_TRY(hipSetDevice(c->device));
   const int ns = b->n_states, n = b->n_qubits, stride = n + 1;
   auto pad16 = [](int x) { return (x + 15) / 16 * 16; };

@@ -74,7 +74,7 @@ _SIGNATURES = [
     ("qk_debug_profile", C.c_int, [_P, _P]),
     ("qk_debug_mma_bench", C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double)]),
     ("qk_selftest_mfma", C.c_int, [_P]),
-    ("qk_build_mps", C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P, C.c_double, C.c_double, C.c_int32, C.POINTER(_P)]),
+    ("qk_build_mps", C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P, C.c_double, C.c_double, C.c_int32, C.c_uint32, C.POINTER(_P)]),
     ("qk_built_info", C.c_int, [_P, _P, _P, _P, C.POINTER(C.c_int64), C.POINTER(C.c_double)]),
     ("qk_built_download", C.c_int, [_P, _P]),
     ("qk_built_destroy", C.c_int, [_P]),
@@ -306,10 +306,12 @@ class Context:
         _check(lib().qk_debug_jacobi(self._h, p, q, a.ctypes.data, v.ctypes.data, sig.ctypes.data, order.ctypes.data), "qk_debug_jacobi")
         return a, v, sig, order
 
-    def build_mps(self, circuits, truncation_fidelity: float = 1.0 - 1e-16, value_of_zero: float = 1e-16, max_bond: int = 256):
+    def build_mps(self, circuits, truncation_fidelity: float = 1.0 - 1e-16, value_of_zero: float = 1e-16, max_bond: int = 256, partial: bool = False):
         """Device MPS builder (/root/reference/gpu_backend/kernel_state_ansatz.py:221, 263): the MPS of every
         bound circuit of the list (``ansatz.BoundCircuit``; they must share one gate structure, as the data points of one
-        ansatz do) in ONE launch.  Returns (list[MPS], info) with info = {"kernel_ms", "total_complex"}."""
+        ansatz do) in ONE launch.  Returns (list[MPS], info) with info = {"kernel_ms", "total_complex", "dropped"}.  With
+        ``partial`` a state that outgrows ``max_bond`` does not fail the call: its entry in the list is ``None`` and its index is
+        in info["dropped"] (build it with the host builder)."""
         from .mps import MPS
 
         circuits = list(circuits)
@@ -325,7 +327,7 @@ class Context:
         n, ns = int(c0.n_qubits), len(circuits)
         h = _P()
         _check(lib().qk_build_mps(self._h, ns, n, int(op.shape[0]), op.ctypes.data, q0.ctypes.data, alpha.ctypes.data,
-                                  max(0.0, 1.0 - float(truncation_fidelity)), float(value_of_zero), int(max_bond), C.byref(h)), "qk_build_mps")
+                                  max(0.0, 1.0 - float(truncation_fidelity)), float(value_of_zero), int(max_bond), 1 if partial else 0, C.byref(h)), "qk_build_mps")
         try:
             dims = np.zeros((ns, n + 1), dtype=np.int32)
             fid = np.zeros(ns, dtype=np.float64)
@@ -336,15 +338,19 @@ class Context:
             _check(lib().qk_built_download(h, flat.ctypes.data), "qk_built_download")
         finally:
             lib().qk_built_destroy(h)
-        states = []
+        states, dropped = [], []
         for s_ in range(ns):
+            if fid[s_] < 0:
+                states.append(None)
+                dropped.append(s_)
+                continue
             pos, tensors = int(offs[s_]), []
             for k in range(n):
                 sz = int(dims[s_, k]) * 2 * int(dims[s_, k + 1])
                 tensors.append(flat[pos : pos + sz].reshape(int(dims[s_, k]), 2, int(dims[s_, k + 1])))
                 pos += sz
             states.append(MPS(tensors, float(fid[s_])))
-        return states, {"kernel_ms": ms.value, "total_complex": int(total.value)}
+        return states, {"kernel_ms": ms.value, "total_complex": int(total.value), "dropped": dropped}
 
     def build_mps_set(self, circuits, truncation_fidelity: float = 1.0 - 1e-16, value_of_zero: float = 1e-16, max_bond: int = 256):
         """Like ``build_mps`` but the states never leave the device: returns (MpsSet, info) with info = {"kernel_ms", "dims",
@@ -362,7 +368,7 @@ class Context:
         n, ns = int(c0.n_qubits), len(circuits)
         h, hs = _P(), _P()
         _check(lib().qk_build_mps(self._h, ns, n, int(op.shape[0]), op.ctypes.data, q0.ctypes.data, alpha.ctypes.data,
-                                  max(0.0, 1.0 - float(truncation_fidelity)), float(value_of_zero), int(max_bond), C.byref(h)), "qk_build_mps")
+                                  max(0.0, 1.0 - float(truncation_fidelity)), float(value_of_zero), int(max_bond), 0, C.byref(h)), "qk_build_mps")
         try:
             dims = np.zeros((ns, n + 1), dtype=np.int32)
             fid = np.zeros(ns, dtype=np.float64)

@@ -59,8 +59,9 @@ def _simulate_share(ansatz, points, rank, n_procs, fidelity, is_root, label):
         # bonds capped at 64 (the regime where it wins) and hands the share to the host builder if a state outgrows that.
         t0 = time.perf_counter()
         cap = int(os.environ.get("QK_BUILDER_MAX_BOND", "256" if which == "device" else "64"))
+        circuits = [ansatz.circuit_for_data(points[k, :]) for k in range(lo, hi)]
         try:
-            states, _ = _engine.default_context().build_mps([ansatz.circuit_for_data(points[k, :]) for k in range(lo, hi)], fidelity, max_bond=cap)
+            states, binfo = _engine.default_context().build_mps(circuits, fidelity, max_bond=cap, partial=(which == "auto"))
         except _engine.QkError as exc:
             if which == "device":
                 raise
@@ -68,8 +69,15 @@ def _simulate_share(ansatz, points, rank, n_procs, fidelity, is_root, label):
             states = None
         if states is not None:
             dt = (time.perf_counter() - t0) / (hi - lo)
+            secs = [dt] * (hi - lo)
+            if binfo["dropped"]:  # states whose bonds outgrew the cap: the host builder is the better tool for those
+                _say(is_root, f"{label}: {len(binfo['dropped'])} of {hi - lo} states outgrew bond {cap}; building them on the host")
+                for k in binfo["dropped"]:
+                    t1 = time.perf_counter()
+                    states[k] = simulate(circuits[k], fidelity)
+                    secs[k] = time.perf_counter() - t1
             _say(is_root, f"{label}: 100%")
-            return lo, states, [dt] * (hi - lo)
+            return lo, states, secs
     states, secs = [], []
     tick = max(1, per_rank // 10)
     for k in range(lo, hi):

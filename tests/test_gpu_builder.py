@@ -153,9 +153,32 @@ def test_auto_builder_falls_back_to_the_host(built, monkeypatch, capsys):
     monkeypatch.setenv("QK_BUILDER", "auto")
     monkeypatch.setenv("QK_BUILDER_MAX_BOND", "4")
     K = build_kernel_matrix(SingleComm(), ans, X=g["X_train"], truncation_error=1e-16)
-    assert "building on the host" in capsys.readouterr().out
+    assert "on the host" in capsys.readouterr().out
     assert np.abs(K - g["K_train"]).max() < 1e-8
     monkeypatch.setenv("QK_BUILDER_MAX_BOND", "64")
     K2 = build_kernel_matrix(SingleComm(), ans, X=g["X_train"], truncation_error=1e-16)
-    assert "building on the host" not in capsys.readouterr().out
+    assert "on the host" not in capsys.readouterr().out
     assert np.abs(K2 - g["K_train"]).max() < 1e-8
+
+
+def test_partial_build_drops_outgrown_states(gpu_ctx):
+    """partial=True: a state that outgrows max_bond is dropped (None, listed in info["dropped"]); the others are complete."""
+    import qml_cutensornet_amd as Q
+    from oracle import restatement as R
+
+    n, reps, d = 12, 3, 2
+    X = R.synthetic_features(8, n, 4)
+    X[0] = X[1] = 2.0  # features at 2 give exponents 0: product states, bonds of 1
+    ans = Q.KernelStateAnsatz(n, reps, 1.0, Q.entanglement_graph(n, d))
+    circuits = [ans.circuit_for_data(x) for x in X]
+    full, _ = gpu_ctx.build_mps(circuits)
+    cap = 8
+    part, info = gpu_ctx.build_mps(circuits, max_bond=cap, partial=True)
+    big = [i for i, m in enumerate(full) if m.max_bond() > cap]
+    assert big and len(big) < len(circuits)
+    assert set(big) <= set(info["dropped"])  # (a transient bond may exceed the cap even if the final ones do not)
+    for i, m in enumerate(part):
+        if i in info["dropped"]:
+            assert m is None
+        else:
+            assert m.max_bond() <= cap and abs(abs(R.mps_inner(m.tensors, full[i].tensors)) ** 2 - 1) < 1e-10
