@@ -51,12 +51,13 @@ def _simulate_share(ansatz, points, rank, n_procs, fidelity, is_root, label):
     per_rank = -(-len(points) // n_procs)
     lo = min(len(points), rank * per_rank)
     hi = min(len(points), lo + per_rank)
-    which = os.environ.get("QK_BUILDER", "host")
+    which = os.environ.get("QK_BUILDER", "auto")  # auto | device | host
     if which in ("device", "auto") and hi > lo:
         # the rank's whole share in ONE launch of the device builder (csrc/qk_build.hip): what the reference does with
         # simulate(libhandle, ...) on the rank's GPU (ref :221,:263).  Pays off at the small bonds of the reference's own
-        # runs (profiles/r01/device_builder_bench.txt); the host builder stays the default.  "auto" tries the device with
-        # bonds capped at 64 (the regime where it wins) and hands the share to the host builder if a state outgrows that.
+        # runs (profiles/r01/device_builder_bench.txt).  "auto" (the default) runs the device builder with bonds capped at 64
+        # -- the regime where it wins -- and builds only the states that outgrow the cap with the host builder, as this
+        # loop always did; "host" skips the device builder, "device" uses it alone (max_bond 256) and fails on overflow.
         t0 = time.perf_counter()
         cap = int(os.environ.get("QK_BUILDER_MAX_BOND", "256" if which == "device" else "64"))
         circuits = [ansatz.circuit_for_data(points[k, :]) for k in range(lo, hi)]
