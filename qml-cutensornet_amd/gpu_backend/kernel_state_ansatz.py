@@ -44,7 +44,7 @@ def _say(is_root, text):
         sys.stdout.flush()
 
 
-def _simulate_share(ansatz, points, rank, n_procs, fidelity, is_root, label):
+def _simulate_share(ansatz, points, rank, n_procs, fidelity, is_root, label, device_id=0):
     """This rank's slice of the data set -> MPS (contiguous chunks of ceil(N/P), as ref :154,:171-174)."""
     import os
 
@@ -62,7 +62,7 @@ def _simulate_share(ansatz, points, rank, n_procs, fidelity, is_root, label):
         cap = int(os.environ.get("QK_BUILDER_MAX_BOND", "256" if which == "device" else "64"))
         circuits = [ansatz.circuit_for_data(points[k, :]) for k in range(lo, hi)]
         try:
-            states, binfo = _engine.default_context().build_mps(circuits, fidelity, max_bond=cap, partial=(which == "auto"))
+            states, binfo = _engine.default_context(device_id).build_mps(circuits, fidelity, max_bond=cap, partial=(which == "auto"))
         except _engine.QkError as exc:
             if which == "device":
                 raise
@@ -177,11 +177,11 @@ def build_kernel_matrix(mpi_comm, ansatz, X, Y=None, info_file=None, truncation_
     # circuits are bound lazily inside the simulation loop; the reference times their generation apart
     prof["r0_circ_gen"] = [0.0, "seconds"]
     _say(is_root, "\nContracting the MPS of the circuits from the X dataset...")
-    x_lo, x_mine, x_secs = _simulate_share(ansatz, X, rank, n_procs, fidelity, is_root, "X")
+    x_lo, x_mine, x_secs = _simulate_share(ansatz, X, rank, n_procs, fidelity, is_root, "X", device_id)
     y_lo, y_mine, y_secs = (0, [], [])
     if Y is not None:
         _say(is_root, "\nContracting the MPS of the circuits from the Y dataset...")
-        y_lo, y_mine, y_secs = _simulate_share(ansatz, Y, rank, n_procs, fidelity, is_root, "Y")
+        y_lo, y_mine, y_secs = _simulate_share(ansatz, Y, rank, n_procs, fidelity, is_root, "Y", device_id)
     sim_secs = x_secs + y_secs
 
     t0 = time.perf_counter()
