@@ -75,6 +75,7 @@ struct BuildArgs {
   int jl_offset;  // doubles from the start of the dynamic LDS to the Jacobi working set
   int jl_elems;   // complex elements it holds
   int partial;    // a state that outgrows cap is dropped (fidelity -1) instead of failing the call
+  const int32_t* order;  // queue position -> state index: states expected to be expensive first
 };
 
 // Shared scalars of a workgroup (one instance in LDS).
@@ -487,8 +488,9 @@ __global__ __launch_bounds__(BT, 2) void qk_build_kernel(const BuildArgs g) {
   for (;;) {
     if (tid == 0) sh.state = (int)atomicAdd(g.counter, 1ull);
     __syncthreads();
-    const int st = sh.state;
+    const int slot_no = sh.state;
     __syncthreads();
+    const int st = (slot_no < g.n_states) ? g.order[slot_no] : slot_no;
     if (st >= g.n_states) {
       if (tid == 0) atomicAdd(reinterpret_cast<unsigned long long*>(g.error + 12), (unsigned long long)(wall_clock64() - wg_begin));  // busy ticks
       break;
@@ -780,9 +782,10 @@ extern "C" int qk_build_mps(qk_ctx* c, int32_t n_states, int32_t n_qubits, int32
   long long* d_offs = nullptr;
   unsigned long long* d_ctr = nullptr;  // [0] state counter, [1] heap top
   int* d_err = nullptr;
+  int32_t* d_order = nullptr;
   auto release = [&]() {
     (void)hipFree(arena), (void)hipFree(work), (void)hipFree(d_op), (void)hipFree(d_q0), (void)hipFree(d_alpha), (void)hipFree(d_fid);
-    (void)hipFree(d_dims), (void)hipFree(d_offs), (void)hipFree(d_ctr), (void)hipFree(d_err);
+    (void)hipFree(d_dims), (void)hipFree(d_offs), (void)hipFree(d_ctr), (void)hipFree(d_err), (void)hipFree(d_order);
   };
 #define BUILD_TRY(expr)                                                                                   \
   do {                                                                                                    \
@@ -811,7 +814,24 @@ extern "C" int qk_build_mps(qk_ctx* c, int32_t n_states, int32_t n_qubits, int32
   }
   BUILD_TRY(hipMemsetAsync(d_ctr, 0, 2 * sizeof(unsigned long long), c->stream));
   BUILD_TRY(hipMemsetAsync(d_err, 0, 16 * sizeof(int), c->stream));
+  // Queue order: longest expected first.  The cost of a state grows with its bonds, and those with the entangling power
+  // of its XXPhase gates, sin^2(pi alpha) summed over the gates -- a cheap proxy that keeps the tail of the launch short.
+  std::vector<int32_t> order(n_states);
+  {
+    std::vector<double> proxy(n_states, 0.0);
+    for (int s = 0; s < n_states; ++s)
+      for (int i = 0; i < n_ops; ++i)
+        if (op[i] == OP_XX) {
+          const double sn = std::sin(M_PI * alpha[(size_t)s * n_ops + i]);
+          proxy[s] += sn * sn;
+        }
+    for (int s = 0; s < n_states; ++s) order[s] = s;
+    if (!std::getenv("QK_BUILD_NO_ORDER")) std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return proxy[x] > proxy[y]; });
+  }
+  BUILD_TRY(hipMalloc(&d_order, (size_t)n_states * sizeof(int32_t)));
+  BUILD_TRY(hipMemcpyAsync(d_order, order.data(), (size_t)n_states * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
   BuildArgs a;
+  a.order = d_order;
   a.n_states = n_states, a.n_qubits = n_qubits, a.n_ops = n_ops, a.cap = cap;
   a.op = d_op, a.q0 = d_q0, a.alpha = d_alpha;
   a.budget = trunc_budget, a.zero = value_of_zero;
