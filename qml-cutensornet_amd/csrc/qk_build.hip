@@ -276,8 +276,11 @@ __device__ void jacobi_orth(P A, const long rs, const long cs, const int p, cons
 // The same factorisation with the working set in LDS when it fits (A and V side by side, odd leading dimension so
 // that the 16 lanes of a pair hit 16 different banks): a step is then a few hundred cycles instead of a store-drain +
 // L2 round trip.  Results are copied back to the global A (same strides) and to V (row-major, ld q).
-__device__ void jacobi_auto(cd* A, const long rs, const long cs, const int p, const int q, cd* V, double* sig, int* ord, WgShared* sh,
-                            int* error, cd* lds, const int lds_elems, cd* scratch) {
+// (Inlined into the kernel so that the kernel's register budget -- MINWG workgroups per CU -- governs it; the variant that
+// keeps 8 rows per lane in registers exists only at 2 workgroups per CU.)
+template <int MINWG>
+__device__ __forceinline__ void jacobi_auto(cd* A, const long rs, const long cs, const int p, const int q, cd* V, double* sig, int* ord, WgShared* sh,
+                                            int* error, cd* lds, const int lds_elems, cd* scratch) {
   const int ld = q | 1;
   if (threadIdx.x == 0) atomicAdd(error + (((long)(p + q) * ld <= lds_elems) ? 5 : 6), 1);  // statistics: LDS-resident / L2-resident
   if ((long)(p + q) * ld <= lds_elems) {
@@ -322,7 +325,7 @@ __device__ void jacobi_auto(cd* A, const long rs, const long cs, const int p, co
 #ifndef QK_BUILD_NO_REGS
       if (rows <= 2) jacobi_orth<lds_cd_ptr, 2>(la, ld, 1, p, q, lv, ld, 1, sig, ord, sh, error, false);
       else if (rows <= 4) jacobi_orth<lds_cd_ptr, 4>(la, ld, 1, p, q, lv, ld, 1, sig, ord, sh, error, false);
-      else if (rows <= 8) jacobi_orth<lds_cd_ptr, 8>(la, ld, 1, p, q, lv, ld, 1, sig, ord, sh, error, false);
+      else if (MINWG <= 2 && rows <= 8) jacobi_orth<lds_cd_ptr, (MINWG <= 2 ? 8 : 4)>(la, ld, 1, p, q, lv, ld, 1, sig, ord, sh, error, false);
       else
 #endif
         jacobi_orth<lds_cd_ptr, 0>(la, ld, 1, p, q, lv, ld, 1, sig, ord, sh, error, false);
@@ -470,7 +473,8 @@ __device__ void wg_kept(const double* sig, const int* ord, const int n, const do
   __syncthreads();
 }
 
-__global__ __launch_bounds__(BT, 2) void qk_build_kernel(const BuildArgs g) {
+template <int MINWG>  // resident workgroups per CU the register budget is cut for: 2 (76 KiB of LDS each) or 4 (38 KiB)
+__global__ __launch_bounds__(BT, MINWG) void qk_build_kernel(const BuildArgs g) {
   extern __shared__ double sh_raw[];
   const int n = g.n_qubits, cap = g.cap, tid = threadIdx.x;
   double* sig = sh_raw;                                   // [2 cap]
@@ -536,7 +540,7 @@ __global__ __launch_bounds__(BT, 2) void qk_build_kernel(const BuildArgs g) {
         cd* u = sites + (centre + 1) * slot;
         const int l = dims[centre], r = dims[centre + 1], r2 = dims[centre + 2];
         const int m = 2 * l;
-        jacobi_auto(t, r, 1, m, r, VV, sig, ord, &sh, g.error, jl, g.jl_elems, TMP);
+        jacobi_auto<MINWG>(t, r, 1, m, r, VV, sig, ord, &sh, g.error, jl, g.jl_elems, TMP);
         if (tid == 0) {
           int k = 0;
           const double smax = sig[ord[0]];
@@ -567,7 +571,7 @@ __global__ __launch_bounds__(BT, 2) void qk_build_kernel(const BuildArgs g) {
         const int l = dims[centre], r = dims[centre + 1], l0 = dims[centre - 1];
         const int w = 2 * r;
         // A(i = (p, c), j = a) = t[a][i]: rs = 1, cs = w
-        jacobi_auto(t, 1, w, w, l, VV, sig, ord, &sh, g.error, jl, g.jl_elems, TMP);
+        jacobi_auto<MINWG>(t, 1, w, w, l, VV, sig, ord, &sh, g.error, jl, g.jl_elems, TMP);
         if (tid == 0) {
           int k = 0;
           const double smax = sig[ord[0]];
@@ -622,8 +626,8 @@ __global__ __launch_bounds__(BT, 2) void qk_build_kernel(const BuildArgs g) {
       // ---- SVD of theta[m x nn] by one-sided Jacobi on its smaller side
       const bool cols = (nn <= m);
       const int qd = cols ? nn : m;
-      if (cols) jacobi_auto(TH, nn, 1, m, nn, VV, sig, ord, &sh, g.error, jl, g.jl_elems, TMP);
-      else jacobi_auto(TH, 1, nn, nn, m, VV, sig, ord, &sh, g.error, jl, g.jl_elems, TMP);
+      if (cols) jacobi_auto<MINWG>(TH, nn, 1, m, nn, VV, sig, ord, &sh, g.error, jl, g.jl_elems, TMP);
+      else jacobi_auto<MINWG>(TH, 1, nn, nn, m, VV, sig, ord, &sh, g.error, jl, g.jl_elems, TMP);
       wg_kept(sig, ord, qd, g.budget, g.zero, &sh);
       int keep = sh.keep;
       fidelity *= sh.frac;
@@ -758,13 +762,19 @@ extern "C" int qk_build_mps(qk_ctx* c, int32_t n_states, int32_t n_qubits, int32
   size_t lds_meta = (size_t)2 * cap * sizeof(double) + (size_t)2 * cap * sizeof(int) + (size_t)(n_qubits + 1) * sizeof(int);
   lds_meta = (lds_meta + 15) / 16 * 16;
   if (lds_meta > 24 * 1024) return qk_fail(QK_EINVAL, "qk_build_mps: %d qubits at max_bond %d need %zu bytes of LDS", n_qubits, cap, lds_meta);
-  size_t lds_total = 76 * 1024;  // two workgroups per CU; what the bookkeeping leaves is the Jacobi working set (A and V of a
-                                 // factorisation up to ~(p + q) q = 4500 complex numbers, e.g. 74 x 37; larger ones run from L2)
-  if (const char* v = std::getenv("QK_BUILD_LDS_KB")) lds_total = (size_t)std::max(32, std::min(156, std::atoi(v))) * 1024;
+  // Two workgroups per CU with 76 KiB of LDS each (what the bookkeeping leaves is the Jacobi working set: A and V of a
+  // factorisation up to ~(p + q) q = 4500 complex numbers, e.g. 74 x 37; larger ones run from L2) -- or, when the caller
+  // bounds the bonds by 32, four with 38 KiB and half the registers each: more latency hiding for small factorisations
+  // (cfg5-shaped: 8.0 instead of 10.4 s), worse as soon as many of them spill to the L2 path.  QK_BUILD_WGS=2|4 overrides.
+  int wgs_variant = (cap <= 32) ? 4 : 2;
+  if (const char* v = std::getenv("QK_BUILD_WGS")) wgs_variant = (std::atoi(v) >= 4) ? 4 : 2;
+  size_t lds_total = (wgs_variant == 4 ? 38 : 76) * 1024;
+  if (const char* v = std::getenv("QK_BUILD_LDS_KB")) lds_total = (size_t)std::max(32, std::min(wgs_variant == 4 ? 38 : 156, std::atoi(v))) * 1024;
   const int jl_elems = (int)((lds_total - lds_meta) / sizeof(cd));
   const size_t lds = lds_total;
-  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(qk_build_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  const int wgs_per_cu = (int)std::min<size_t>(4, (160 * 1024) / (lds_total + 1024));  // + the static LDS of the kernel
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(qk_build_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(qk_build_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 38 * 1024));
+  const int wgs_per_cu = std::min(wgs_variant, (int)((160 * 1024) / (lds_total + 1024)));  // + the static LDS of the kernel
   size_t free_b = 0, total_b = 0;
   HIP_TRY(hipMemGetInfo(&free_b, &total_b));
   const size_t per_wg = ((size_t)n_qubits * 2 * cap * cap + (size_t)3 * 4 * cap * cap) * sizeof(cd);
@@ -840,7 +850,8 @@ extern "C" int qk_build_mps(qk_ctx* c, int32_t n_states, int32_t n_qubits, int32
   a.jl_offset = (int)(lds_meta / sizeof(double)), a.jl_elems = jl_elems;
   a.partial = (flags & QK_BUILD_PARTIAL) ? 1 : 0;
   BUILD_TRY(hipEventRecord(c->ev0, c->stream));
-  qk_build_kernel<<<dim3((unsigned)grid), dim3(BT), lds, c->stream>>>(a);
+  if (wgs_variant == 4) qk_build_kernel<4><<<dim3((unsigned)grid), dim3(BT), lds, c->stream>>>(a);
+  else qk_build_kernel<2><<<dim3((unsigned)grid), dim3(BT), lds, c->stream>>>(a);
   BUILD_TRY(hipGetLastError());
   BUILD_TRY(hipEventRecord(c->ev1, c->stream));
   qk_built* b = new qk_built;
