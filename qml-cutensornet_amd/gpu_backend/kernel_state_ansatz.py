@@ -27,13 +27,13 @@ try:  # normal case: imported as qml_cutensornet_amd.gpu_backend.kernel_state_an
     from ..ansatz import KernelStateAnsatz  # noqa: F401
     from .. import engine as _engine
     from ..dist import assemble_gram, comm_allgather
-    from ..mps import MPS, simulate
+    from ..mps import MPS, simulate, simulate_many  # noqa: F401
 except ImportError:  # imported top-level as gpu_backend.kernel_state_ansatz
     import qml_cutensornet_amd as _pkg  # noqa: F401
     from qml_cutensornet_amd.ansatz import KernelStateAnsatz  # noqa: F401
     from qml_cutensornet_amd import engine as _engine
     from qml_cutensornet_amd.dist import assemble_gram, comm_allgather
-    from qml_cutensornet_amd.mps import MPS, simulate
+    from qml_cutensornet_amd.mps import MPS, simulate, simulate_many  # noqa: F401
 
 ROOT_RANK = 0
 
@@ -44,7 +44,7 @@ def _say(is_root, text):
         sys.stdout.flush()
 
 
-def _simulate_share(ansatz, points, rank, n_procs, fidelity, is_root, label, device_id=0):
+def _simulate_share(ansatz, points, rank, n_procs, fidelity, is_root, label, device_id=0, host_workers=1):
     """This rank's slice of the data set -> MPS (contiguous chunks of ceil(N/P), as ref :154,:171-174)."""
     import os
 
@@ -73,20 +73,21 @@ def _simulate_share(ansatz, points, rank, n_procs, fidelity, is_root, label, dev
             secs = [dt] * (hi - lo)
             if binfo["dropped"]:  # states whose bonds outgrew the cap: the host builder is the better tool for those
                 _say(is_root, f"{label}: {len(binfo['dropped'])} of {hi - lo} states outgrew bond {cap}; building them on the host")
-                for k in binfo["dropped"]:
-                    t1 = time.perf_counter()
-                    states[k] = simulate(circuits[k], fidelity)
-                    secs[k] = time.perf_counter() - t1
+                built, bsecs = simulate_many([circuits[k] for k in binfo["dropped"]], fidelity, workers=host_workers)
+                for k, m, dt_k in zip(binfo["dropped"], built, bsecs):
+                    states[k], secs[k] = m, dt_k
             _say(is_root, f"{label}: 100%")
             return lo, states, secs
-    states, secs = [], []
-    tick = max(1, per_rank // 10)
-    for k in range(lo, hi):
-        t0 = time.perf_counter()
-        states.append(simulate(ansatz.circuit_for_data(points[k, :]), fidelity))
-        secs.append(time.perf_counter() - t0)
-        if (k - lo) % tick == 0:
-            _say(is_root, f"{label}: {10 * ((k - lo) // tick)}%")
+    # host builder: one circuit per core on a thread pool (no fork: the GPU may already be initialised; the native builder
+    # releases the GIL) -- the reference's loop is serial because its simulate() runs on the GPU (ref :213-231)
+    tick, done = max(1, per_rank // 10), [0]
+
+    def progress():
+        done[0] += 1
+        if (done[0] - 1) % tick == 0:
+            _say(is_root, f"{label}: {10 * ((done[0] - 1) // tick)}%")
+
+    states, secs = simulate_many([ansatz.circuit_for_data(points[k, :]) for k in range(lo, hi)], fidelity, workers=host_workers, progress=progress)
     return lo, states, secs
 
 
@@ -167,6 +168,9 @@ def build_kernel_matrix(mpi_comm, ansatz, X, Y=None, info_file=None, truncation_
     if n_dev <= 0:
         raise _engine.QkError("no gfx950 device visible: the Gram path has no CPU fallback")
     device_id = rank % n_dev
+    from qml_cutensornet_amd.builder_pool import default_workers
+
+    host_workers = max(1, default_workers() // max(1, min(n_procs, n_dev)))  # host cores of this rank's share of the node
     prof = {}
     t_start = time.perf_counter()
     if is_root:
@@ -177,11 +181,11 @@ def build_kernel_matrix(mpi_comm, ansatz, X, Y=None, info_file=None, truncation_
     # circuits are bound lazily inside the simulation loop; the reference times their generation apart
     prof["r0_circ_gen"] = [0.0, "seconds"]
     _say(is_root, "\nContracting the MPS of the circuits from the X dataset...")
-    x_lo, x_mine, x_secs = _simulate_share(ansatz, X, rank, n_procs, fidelity, is_root, "X", device_id)
+    x_lo, x_mine, x_secs = _simulate_share(ansatz, X, rank, n_procs, fidelity, is_root, "X", device_id, host_workers)
     y_lo, y_mine, y_secs = (0, [], [])
     if Y is not None:
         _say(is_root, "\nContracting the MPS of the circuits from the Y dataset...")
-        y_lo, y_mine, y_secs = _simulate_share(ansatz, Y, rank, n_procs, fidelity, is_root, "Y", device_id)
+        y_lo, y_mine, y_secs = _simulate_share(ansatz, Y, rank, n_procs, fidelity, is_root, "Y", device_id, host_workers)
     sim_secs = x_secs + y_secs
 
     t0 = time.perf_counter()

@@ -192,6 +192,52 @@ def simulate(circuit: BoundCircuit, truncation_fidelity: float = 1.0 - 1e-16, va
         return _simulate(circuit, truncation_fidelity, value_of_zero)
 
 
+def simulate_many(circuits, truncation_fidelity: float = 1.0 - 1e-16, value_of_zero: float = 1e-16, workers: int | None = None, progress=None):
+    """``simulate`` for a list of circuits on several host cores **without forking** (safe once the GPU is initialised):
+    the native builder is a ctypes call that releases the GIL, so a thread pool runs one circuit per core; LAPACK stays
+    single-threaded inside each call.  Falls back to the serial loop when the native builder is unavailable.
+    Returns (list[MPS], seconds per circuit)."""
+    import time
+
+    circuits = list(circuits)
+    if workers is None:
+        from .builder_pool import default_workers
+
+        workers = default_workers()
+    workers = max(1, min(int(workers), len(circuits)))
+
+    def one(c):
+        t0 = time.perf_counter()
+        m = simulate_native(c, truncation_fidelity, value_of_zero)
+        if progress is not None:
+            progress()
+        return m, time.perf_counter() - t0
+
+    if workers > 1 and _use_native():
+        from concurrent.futures import ThreadPoolExecutor
+
+        try:
+            from threadpoolctl import threadpool_limits
+        except ImportError:  # pragma: no cover - optional dependency
+            threadpool_limits = None
+        ctx = threadpool_limits(limits=1) if threadpool_limits else None
+        try:
+            with ThreadPoolExecutor(max_workers=workers) as pool:
+                res = list(pool.map(one, circuits))
+        finally:
+            if ctx is not None:
+                ctx.restore_original_limits()
+        return [m for m, _ in res], [dt for _, dt in res]
+    out, secs = [], []
+    for c in circuits:
+        t0 = time.perf_counter()
+        out.append(simulate(c, truncation_fidelity, value_of_zero))
+        secs.append(time.perf_counter() - t0)
+        if progress is not None:
+            progress()
+    return out, secs
+
+
 def _use_native() -> bool:
     """QK_NATIVE_BUILDER=0 forces the numpy/scipy loop; otherwise the native builder is used when it loads."""
     import os

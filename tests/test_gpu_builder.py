@@ -182,3 +182,17 @@ def test_partial_build_drops_outgrown_states(gpu_ctx):
             assert m is None
         else:
             assert m.max_bond() <= cap and abs(abs(R.mps_inner(m.tensors, full[i].tensors)) ** 2 - 1) < 1e-10
+
+
+def test_build_kernel_matrix_with_host_builder_pool(built, monkeypatch):
+    """QK_BUILDER=host: the module surface builds its states with the threaded host builder."""
+    import qml_cutensornet_amd as Q
+    from qml_cutensornet_amd.dist import SingleComm
+    from qml_cutensornet_amd.gpu_backend.kernel_state_ansatz import KernelStateAnsatz, build_kernel_matrix
+
+    monkeypatch.setenv("QK_BUILDER", "host")
+    g = golden("cfg2_20q_r2_d1_subset.npz")
+    n, reps, gamma = int(g["n"]), int(g["reps"]), float(g["gamma"])
+    ans = KernelStateAnsatz(num_qubits=n, reps=reps, gamma=gamma, entanglement_map=Q.entanglement_graph(n, int(g["d"])), hadamard_init=True)
+    K = build_kernel_matrix(SingleComm(), ans, X=g["X_train"], truncation_error=1e-16)
+    assert np.abs(K - g["K_train"]).max() < 1e-10

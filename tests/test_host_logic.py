@@ -371,3 +371,27 @@ def test_simulate_falls_back_without_native(monkeypatch):
     monkeypatch.setenv("QK_NATIVE_BUILDER", "1")
     b = Q.simulate(c)
     assert (a.bond_dims() == b.bond_dims()).all()
+
+
+def test_simulate_many_matches_simulate(monkeypatch):
+    """The fork-free thread pool over the native builder gives the same states as the serial loop, in order."""
+    import numpy as np
+
+    import qml_cutensornet_amd as Q
+    from oracle import restatement as R
+    from qml_cutensornet_amd import mps as M
+
+    X = R.synthetic_features(9, 12, 2)
+    ans = Q.KernelStateAnsatz(12, 2, 1.0, Q.entanglement_graph(12, 2))
+    circuits = [ans.circuit_for_data(x) for x in X]
+    ref = [M.simulate(c) for c in circuits]
+    ticks = []
+    many, secs = M.simulate_many(circuits, workers=4, progress=lambda: ticks.append(1))
+    assert len(many) == len(secs) == len(ticks) == len(ref) and all(s > 0 for s in secs)
+    for a, b in zip(many, ref):
+        assert np.array_equal(a.bond_dims(), b.bond_dims())
+        assert abs(abs(R.mps_inner(a.tensors, b.tensors)) ** 2 - 1) < 1e-12
+    monkeypatch.setenv("QK_NATIVE_BUILDER", "0")  # numpy loop: serial path
+    serial, _ = M.simulate_many(circuits[:3], workers=4)
+    for a, b in zip(serial, ref):
+        assert abs(abs(R.mps_inner(a.tensors, b.tensors)) ** 2 - 1) < 1e-12
