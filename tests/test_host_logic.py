@@ -385,12 +385,15 @@ def test_simulate_many_matches_simulate(monkeypatch):
     ans = Q.KernelStateAnsatz(12, 2, 1.0, Q.entanglement_graph(12, 2))
     circuits = [ans.circuit_for_data(x) for x in X]
     ref = [M.simulate(c) for c in circuits]
-    ticks = []
-    many, secs = M.simulate_many(circuits, workers=4, progress=lambda: ticks.append(1))
-    assert len(many) == len(secs) == len(ticks) == len(ref) and all(s > 0 for s in secs)
-    for a, b in zip(many, ref):
-        assert np.array_equal(a.bond_dims(), b.bond_dims())
-        assert abs(abs(R.mps_inner(a.tensors, b.tensors)) ** 2 - 1) < 1e-12
+    for mode in ("auto", "threads", "procs", "serial"):
+        monkeypatch.setenv("QK_BUILDER_POOL", mode)
+        ticks = []
+        many, secs = M.simulate_many(circuits, workers=3, progress=lambda: ticks.append(1))
+        assert len(many) == len(secs) == len(ticks) == len(ref) and all(s > 0 for s in secs), mode
+        for a, b in zip(many, ref):
+            assert np.array_equal(a.bond_dims(), b.bond_dims())
+            assert abs(abs(R.mps_inner(a.tensors, b.tensors)) ** 2 - 1) < 1e-12
+    monkeypatch.delenv("QK_BUILDER_POOL")
     monkeypatch.setenv("QK_NATIVE_BUILDER", "0")  # numpy loop: serial path
     serial, _ = M.simulate_many(circuits[:3], workers=4)
     for a, b in zip(serial, ref):
