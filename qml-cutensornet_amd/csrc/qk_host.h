@@ -35,6 +35,7 @@ struct qk_ctx {
   int wgs_per_cu = 2;  // resident workgroups per CU (QK_WGS_PER_CU)
   bool wave_path = true;   // fp64 sets whose bonds are all <= 16 use the one-wave-per-pair register sweep (QK_WAVE=0 opts out)
   bool small_path = true;  // sets whose bonds are all <= 32 use the LDS-resident small-bond sweep (QK_SMALL=0 opts out)
+  int fused_path = 1;      // fp64 sets with a bond > 32 use the site-fused sweep (QK_FUSED=0: ring sweep instead; 2: also for bonds 17..32)
   qk_stats last{};
 };
 
@@ -43,6 +44,7 @@ struct qk_mps_set {
   int n_states = 0, n_sites = 0, max_pad = 0;
   int precision = 64;         // bits of a real: 64 (complex128 planes) or 32 (complex64 planes, same element offsets)
   double* d_data = nullptr;   // the planes; floats when precision == 32
+  double* d_il = nullptr;     // fp64 only, made on first use by the site-fused sweep: the same image with re/im interleaved (complex128), same offsets
   int32_t* d_dims = nullptr;  // padded bonds [n_states][n_sites+1]
   int32_t* d_true = nullptr;  // true bonds   [n_states][n_sites+1]
   int64_t* d_offs = nullptr;  // re-plane offsets (doubles) [n_states][n_sites]

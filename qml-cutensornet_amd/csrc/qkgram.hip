@@ -15,6 +15,7 @@
 // Written for gfx950 only: 64-lane wavefronts, 160 KiB LDS per CU, no portability layer.
 #include "qk_host.h"
 #include "qk_ring.h"
+#include "qk_fused.h"
 
 #include <algorithm>
 #include <cmath>
@@ -354,6 +355,7 @@ extern "C" int qk_ctx_create(int device_id, qk_ctx** out) {
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(qk_sweep_ring_kernel<double>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(qk_sweep_small_kernel<double>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(qk_sweep_small_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(qk_sweep_fused_kernel<QKF_NW, QKF_SLOTS>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   {
     const int rc = qk_lab_init(c);
     if (rc != QK_OK) return rc;
@@ -361,6 +363,7 @@ extern "C" int qk_ctx_create(int device_id, qk_ctx** out) {
   if (const char* v = std::getenv("QK_VARIANT")) c->variant = std::atoi(v);
   if (const char* v = std::getenv("QK_SMALL")) c->small_path = std::atoi(v) != 0;
   if (const char* v = std::getenv("QK_WAVE")) c->wave_path = std::atoi(v) != 0;
+  if (const char* v = std::getenv("QK_FUSED")) c->fused_path = std::atoi(v);
   if (const char* v = std::getenv("QK_WGS_PER_CU")) c->wgs_per_cu = std::max(1, std::min(4, std::atoi(v)));
   *out = c;
   return QK_OK;
@@ -463,6 +466,7 @@ extern "C" int qk_mps_set_destroy(qk_mps_set* m) {
   (void)hipSetDevice(m->ctx->device);
   (void)hipStreamSynchronize(m->ctx->stream);
   if (m->d_data) (void)hipFree(m->d_data);
+  if (m->d_il) (void)hipFree(m->d_il);
   if (m->d_dims) (void)hipFree(m->d_dims);
   if (m->d_true) (void)hipFree(m->d_true);
   if (m->d_offs) (void)hipFree(m->d_offs);
@@ -513,6 +517,17 @@ extern "C" int qk_mps_set_to_f32(qk_ctx* c, const qk_mps_set* src, qk_mps_set** 
   return QK_OK;
 }
 
+// the interleaved complex128 image of a set, made once on the device from the split planes
+static int ensure_interleaved(qk_ctx* c, qk_mps_set* m) {
+  if (m->d_il) return QK_OK;
+  if (m->precision != 64) return fail(QK_EINVAL, "the site-fused sweep needs an fp64 set");
+  HIP_TRY(hipMalloc(&m->d_il, (size_t)m->bytes));
+  const long long nt = (long long)m->n_states * m->n_sites;
+  qk_interleave_kernel<<<dim3((unsigned)std::min<long long>(nt, 64ll * c->num_cus)), dim3(256), 0, c->stream>>>(m->d_data, m->d_il, m->d_dims, m->d_offs, m->n_sites, nt);
+  HIP_TRY(hipGetLastError());
+  return QK_OK;
+}
+
 static int ensure_plan_uploaded(qk_ctx* c, qk_plan* p) {
   if (p->d_pairs && p->up_ctx == c) return QK_OK;
   if (p->d_pairs) {
@@ -560,7 +575,12 @@ extern "C" int qk_gram_values(qk_ctx* c, const qk_mps_set* xs, const qk_mps_set*
   const long long x_plane = members * xs->max_pad * ys->max_pad;
   const long long t_plane = 2 * x_plane;
   const long long units = quad ? np / 4 : grouped ? (long long)plan->groups.size() / 2 : (duo ? (np + 1) / 2 : np);
-  const int grid = (int)std::min<long long>(units, (long long)c->wgs_per_cu * c->num_cus);
+  const int max_pad = std::max(xs->max_pad, ys->max_pad);
+  // the site-fused sweep (qk_fused.h): fp64, one workgroup per CU; bonds up to XCAP / 16 = 512 (one 16-row strip of X' must fit the LDS)
+  const size_t lds_fused = (size_t)QKF_XCAP * 16 + 16 + (size_t)(4 * (xs->n_sites + 1) + 2) * sizeof(int) + (size_t)2 * xs->n_sites * sizeof(long long);
+  const bool fused = c->variant == 20 && !f32 && !quad && c->fused_path != 0 && max_pad > (c->fused_path >= 2 ? 16 : 32) &&
+                     max_pad <= QKF_XCAP / TILE && lds_fused <= (size_t)160 * 1024 / (8 / QKF_NW);
+  const int grid = (int)std::min<long long>(units, (long long)(fused ? 8 / QKF_NW : c->wgs_per_cu) * c->num_cus);  // the fused sweep: 8 waves per CU
   const size_t need = (size_t)grid * (size_t)chains * 2 * (size_t)(x_plane + t_plane) * sizeof(double);
   if (need > c->scratch_bytes) {
     HIP_TRY(hipStreamSynchronize(c->stream));
@@ -603,6 +623,16 @@ extern "C" int qk_gram_values(qk_ctx* c, const qk_mps_set* xs, const qk_mps_set*
     // its LDS budget (several hundred sites) take the ring kernel below
     if (f32) qk_sweep_small_kernel<float><<<dim3(grid), dim3(512), lds_small, c->stream>>>(a);
     else qk_sweep_small_kernel<double><<<dim3(grid), dim3(512), lds_small, c->stream>>>(a);
+  } else if (fused) {
+    // X in LDS, T in registers, site tensors read straight into MFMA fragments from the interleaved image
+    for (const qk_mps_set* m : {xs, ys}) {
+      const int rc_il = ensure_interleaved(c, const_cast<qk_mps_set*>(m));
+      if (rc_il != QK_OK) return rc_il;
+    }
+    a.xdata = xs->d_il, a.ydata = ys->d_il;
+    a.x_plane = (long long)xs->max_pad * ys->max_pad;  // complex elements per global X buffer (two per workgroup)
+    HIP_TRY(hipEventRecord(c->ev0, c->stream));        // the conversion above is not part of the sweep
+    qk_sweep_fused_kernel<QKF_NW, QKF_SLOTS><<<dim3(grid), dim3(64 * QKF_NW), lds_fused, c->stream>>>(a);
   } else if (f32) {  // complex64 sweep: the ring kernel on fp32 planes; QK_VARIANT does not apply
     qk_sweep_ring_kernel<float><<<dim3(grid), dim3(512), lds_ring, c->stream>>>(a);
   } else if (c->variant == 20) {  // the shipped kernel: LDS-DMA staging ring (K-tile 8, three slots) + 3M complex product

@@ -458,3 +458,74 @@ def test_large_bonds(gpu_ctx):
     assert np.abs(z - z_ref).max() < TOL
     assert np.abs(np.diag(z) - 1).max() < 1e-12
     assert np.abs(z32 - z_ref).max() < F32_TOL
+
+
+# ------------------------------------------------------------------ the real workloads of cfg4 and cfg5 (BASELINE.json configs[3], [4])
+def _real_states(n, reps, d, gamma, points, seed=5):
+    """The first `points` states of the config's own data set (synthetic features of the FULL set, seed 5), host builder."""
+    import os
+
+    import qml_cutensornet_amd as Q
+    from qml_cutensornet_amd.builder_pool import build_states
+    from qml_cutensornet_amd.data import synthetic_features
+
+    full = {60: 500, 100: 1000}[n]
+    X = synthetic_features(full, n, seed)[:points]
+    ans = Q.KernelStateAnsatz(n, reps, gamma, Q.entanglement_graph(n, d))
+    states, _ = build_states(ans, X, 1 - 1e-16, min(points, os.cpu_count() or 1))
+    return states
+
+
+def _check_real_workload(ctx, states, ny):
+    """Full symmetric Gram + a rectangular slice (the first ny states as Y) against oracle/overlap_ref.c on the same
+    tensors: absolute 1e-11 on z and K, and RELATIVE 1e-9 on every overlap (the off-diagonal overlaps of these sets
+    are tiny; the 3M complex product is only normwise stable in the imaginary part)."""
+    from oracle import c_oracle
+
+    ts = [m.tensors for m in states]
+    n = len(states)
+    pairs = np.array([(i, j) for j in range(n) for i in range(n)], dtype=np.int32)
+    _, z_ref, _ = c_oracle.gram_pairs(ts, None, pairs)
+    z_ref = z_ref.reshape(n, n)
+    with ctx.upload(states) as dx, ctx.upload(states[:ny]) as dy:
+        K = ctx.gram(dx)
+        z = ctx.overlaps(dx)
+        K_rect = ctx.gram(dx, dy)
+    assert np.abs(z - z_ref).max() < TOL
+    assert np.abs(K - np.abs(z_ref) ** 2).max() < TOL
+    assert K_rect.shape == (ny, n) and np.abs(K_rect - np.abs(z_ref[:ny]) ** 2).max() < TOL
+    rel = np.abs(z - z_ref) / np.abs(z_ref)
+    assert rel.max() < 1e-9, (rel.max(), np.abs(z_ref).min())
+    assert np.abs(np.diag(K) - 1).max() < 1e-11 and np.array_equal(K, K.T)
+    return float(np.abs(z_ref).min())
+
+
+def test_cfg4_real_states(gpu_ctx, monkeypatch):
+    """cfg4 (60 qubits x 6 layers, d=2, gamma=1, seed 5): 12 of its 500 states through the shipped path (site-fused
+    sweep) and, on a second context, through the ring sweep."""
+    from qml_cutensornet_amd import engine
+
+    states = _real_states(60, 6, 2, 1.0, 12)
+    assert max(m.max_bond() for m in states) > 64  # matrix-core regime
+    smallest = _check_real_workload(gpu_ctx, states, 5)
+    assert smallest < 1e-3  # the relative bound above was exercised on small overlaps
+    monkeypatch.setenv("QK_FUSED", "0")
+    with engine.context(0) as ctx_ring:
+        _check_real_workload(ctx_ring, states, 5)
+
+
+def test_cfg5_real_states(gpu_ctx, monkeypatch):
+    """cfg5's real circuit (100 qubits x 10 layers, d=4, gamma=0.1, seed 5): 8 of its 1000 states through the small-bond
+    kernel (bonds <= 32), the site-fused sweep (QK_FUSED=2) and the ring sweep (QK_SMALL=0, QK_FUSED=0)."""
+    from qml_cutensornet_amd import engine
+
+    states = _real_states(100, 10, 4, 0.1, 8)
+    assert 16 < max(m.max_bond() for m in states) <= 32
+    _check_real_workload(gpu_ctx, states, 3)
+    monkeypatch.setenv("QK_FUSED", "2")
+    with engine.context(0) as ctx_fused:
+        _check_real_workload(ctx_fused, states, 3)
+    monkeypatch.setenv("QK_FUSED", "0")
+    monkeypatch.setenv("QK_SMALL", "0")
+    with engine.context(0) as ctx_ring:
+        _check_real_workload(ctx_ring, states, 3)

@@ -398,3 +398,61 @@ def test_simulate_many_matches_simulate(monkeypatch):
     serial, _ = M.simulate_many(circuits[:3], workers=4)
     for a, b in zip(serial, ref):
         assert abs(abs(R.mps_inner(a.tensors, b.tensors)) ** 2 - 1) < 1e-12
+
+
+# ------------------------------------------------------------------ bond dimensions: the only aggregate the reference publishes (O5)
+def _reference_feature_pipeline(raw):
+    """main.py:130-143 / main_no_test.py:128-139 restated with sklearn, as the reference runs it:
+    QuantileTransformer(normal) -> StandardScaler -> MinMaxScaler((0, 2))."""
+    import warnings
+
+    from sklearn.preprocessing import MinMaxScaler, QuantileTransformer, StandardScaler
+
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")  # n_quantiles is clipped to the 8 samples, as in the reference's 5+5-point runs
+        x = QuantileTransformer(output_distribution="normal").fit_transform(raw)
+    x = StandardScaler().fit_transform(x)
+    return MinMaxScaler((0, 2)).fit_transform(x)
+
+
+def test_bonds_equal_exact_schmidt_ranks(built):
+    """The builder's bonds ARE the Schmidt ranks of the exact state at the reference's cutoff (relative discarded
+    weight 1e-16, KernelPkg.jl:68 / G:142): 16 qubits, 2 layers, d = 4, every cut of three states."""
+    import qml_cutensornet_amd as Q
+
+    n, reps, d, gamma = 16, 2, 4, 1.0
+    edges = Q.entanglement_graph(n, d)
+    ans = Q.KernelStateAnsatz(n, reps, gamma, edges)
+    for x in R.synthetic_features(3, n, 5):
+        bonds = Q.simulate(ans.circuit_for_data(x), 1 - 1e-16).bond_dims()[1:-1].tolist()
+        psi = R.statevector(n, R.ansatz_gates(x, reps, gamma, edges))
+        ranks = []
+        for k in range(1, n):
+            w = np.linalg.svd(psi.reshape(2**k, -1), compute_uv=False) ** 2
+            tail = np.cumsum(w[::-1])
+            ranks.append(len(w) - int(np.searchsorted(tail, (1 - (1 - 1e-16)) * w.sum(), side="right")))
+        assert bonds == ranks
+
+
+def test_max_bond_against_published_aggregate(built):
+    """O5: /root/reference/runs/crossover/cpu_results.csv:2-6 reports avg_max_chi 10.25 / 29.4 for 100
+    qubits, 2 layers, gamma = 1, d = 2 / 4 over 8 training points of the Elliptic data set (5 + 5 points, 20 % held
+    out).  The data set is not available; the reference's feature pipeline is restated on tie-free synthetic columns.
+    What can be pinned: the analytic bound 2^(d r), growth with d, and the d = 2 figure within a factor 2.  At d >= 4
+    the bond is data-dependent (measured here: 84.8 at d = 4, 470 at d = 6 against 29.4 / 73.6) -- see DESIGN.md."""
+    import qml_cutensornet_amd as Q
+    from qml_cutensornet_amd.builder_pool import build_states
+
+    n, reps, gamma = 100, 2, 1.0
+    X = _reference_feature_pipeline(np.random.default_rng(5).standard_normal((8, n)))
+    assert X.min() == 0.0 and X.max() == 2.0
+    avg = {}
+    for d in (2, 4):
+        ans = Q.KernelStateAnsatz(n, reps, gamma, Q.entanglement_graph(n, d))
+        states, _ = build_states(ans, X, 1 - 1e-16, min(8, os.cpu_count() or 1))
+        mx = np.array([m.max_bond() for m in states])
+        assert mx.max() <= 2 ** (d * reps)
+        assert all(abs(m.fidelity - 1) < 1e-9 for m in states)
+        avg[d] = float(mx.mean())
+    assert 10.25 / 2 <= avg[2] <= 10.25 * 2
+    assert avg[4] > avg[2] and avg[4] >= 29.375 / 2

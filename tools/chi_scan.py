@@ -12,6 +12,8 @@ import qml_cutensornet_amd as Q
 from qml_cutensornet_amd import engine
 
 PEAK = 256 * 4 * 32 * 2.4e9
+if "QK_LIB" in os.environ:  # experiment builds of the library (tools/exp_fused.sh)
+    engine.LIB_PATH = os.environ["QK_LIB"]
 
 
 def profile(n, chi):
