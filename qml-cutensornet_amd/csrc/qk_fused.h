@@ -30,93 +30,109 @@
 typedef double v2d __attribute__((ext_vector_type(2)));
 typedef __attribute__((address_space(3))) v2d lds_v2d;
 
-#ifndef QKF_NW_
-#define QKF_NW_ 8
-#define QKF_SLOTS_ 2
-#endif
-#ifndef QKF_XCAP_
-#define QKF_XCAP_ 8192
-#endif
-static constexpr int QKF_NW = QKF_NW_;        // waves per workgroup (two per SIMD, 256 registers each)
-static constexpr int QKF_XCAP = QKF_XCAP_;   // complex elements of the LDS X buffer (128 KiB)
-static constexpr int QKF_SLOTS = QKF_SLOTS_;     // T slots (items) per wave and phase: 16 VGPRs per tile, two tiles per item
+// Two shapes are shipped (qkgram.hip picks one per launch from the plan's work profile):
+//   <8 waves, 4 slots, 8192-element X buffer>: one workgroup per CU  -- large bonds (more sites stay LDS-resident)
+//   <4 waves, 4 slots, 4608-element X buffer>: two workgroups per CU -- small / medium bonds (the second workgroup
+//                                              fills the first one's barriers and per-site set-up)
+static constexpr int QKF_SLOTS = 4;  // T slots (items) per wave and round: 16 VGPRs each
 
 // one complex k-step, 3M form: (ar + i ai) * (br + i s bi), s = +1 | -1 (CONJB)
 template <bool CONJB>
 __device__ __forceinline__ void qkf_kstep(v4d& p1, v4d& p2, v4d& p3, const double ar, const double ai, const double br, const double bi) {
+#ifdef QKF_EXP_NOMFMA  // timing experiment: everything but the matrix instructions (operands stay live)
+  asm volatile("" ::"v"(ar), "v"(ai), "v"(br), "v"(bi));
+#else
   const double sa = ar + ai, sb = CONJB ? br - bi : br + bi;
   p1 = __builtin_amdgcn_mfma_f64_16x16x4f64(ar, br, p1, 0, 0, 0);
   p2 = __builtin_amdgcn_mfma_f64_16x16x4f64(ai, bi, p2, 0, 0, 0);
   p3 = __builtin_amdgcn_mfma_f64_16x16x4f64(sa, sb, p3, 0, 0, 0);
+#endif
 }
 
-struct QkfTile {
+struct QkfTile {  // a 16 x 16 complex tile in the C/D register layout: 16 VGPRs
   v4d re, im;
 };
 
 // 16-byte fragment load from a wave-uniform base and a 32-bit lane offset (in elements): the addressing form
 // global_load_dwordx4 v, v_off, s[base:base+1] -- one VGPR of address state per stream
 __device__ __forceinline__ v2d qkf_ldg(const v2d* __restrict__ base, const unsigned off) {
+#ifdef QKF_EXP_NOLOAD  // timing experiment: no fragment loads from global memory
+  return (v2d){(double)off, 1.0};
+#else
   return *reinterpret_cast<const v2d*>(reinterpret_cast<const char*>(base) + (size_t)(off * 16u));
+#endif
 }
 __device__ __forceinline__ v2d qkf_ldx(const v2d* __restrict__ base, const unsigned off) { return qkf_ldg(base, off); }
 __device__ __forceinline__ v2d qkf_ldx(const lds_v2d* base, const unsigned off) { return base[off]; }
 
-// Phase 1, one tile: T[ta, p, tb] = sum_{l < 4 nks} X[l][16 ta + .] * B[l][p][16 tb + .].
-//   B operand: element (bp + boff + i * bstep) for k-step i (bp uniform, boff = this lane's element of k-step 0);
+// A fragment stream: k-step i of the current group is element base + off + i * step (base wave-uniform, off this lane's)
+struct QkfStream {
+  const v2d* base;
+  unsigned off;
+  int step;
+};
+__device__ __forceinline__ void qkf_load4(v2d (&fr)[4], const QkfStream& st) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) fr[i] = qkf_ldg(st.base + i * st.step, st.off);
+}
+
+// Phase 1, one tile (= one item): T[ta, p, tb] = sum_{l < 4 nks} X[l][16 ta + .] * B[l][p][16 tb + .].
+//   B operand: stream `cur` (step = one k-step = 4 rows of b); its first group is already in `fr` when `primed`;
 //   A operand: X element (xp + xoff + i * xstep), X in LDS or in the global buffer.
 // Four k-steps of fragments are in flight: the registers of a k-step are reloaded for k-step + 4 right after its
-// MFMAs (sched_barrier keeps that order).  Loads are unconditional (rows up to the padded bond exist and are zero;
-// past the last group the same rows are read again), MFMAs are issued only for the k-steps below the true bond.
+// MFMAs (sched_barrier keeps that order); in the LAST group they are reloaded with the first group of stream `nxt`
+// -- the wave's next tile, or its first phase-2 group -- so the stream never drains between tiles or across the
+// barriers.  Loads are unconditional (rows up to the padded bond exist and are zero), MFMAs are issued only for the
+// k-steps below the true bond.
 template <typename XPtr>
-__device__ __forceinline__ void qkf_p1_tile(v4d& p1, v4d& p2, v4d& p3, const v2d* __restrict__ bp, unsigned boff, const int bstep, XPtr xp, unsigned xoff, const int xstep, const int nks) {
-  p1 = p2 = p3 = (v4d){0, 0, 0, 0};
-  v2d fb[4], fx[4];
+__device__ __forceinline__ void qkf_p1_tile(QkfTile& t, v2d (&fr)[4], const bool primed, QkfStream cur, XPtr xp, unsigned xoff, const int xstep, const int nks, const QkfStream nxt) {
+  v4d p1 = {0, 0, 0, 0}, p2 = {0, 0, 0, 0}, p3 = {0, 0, 0, 0};
+  v2d fx[4];
+  if (!primed) qkf_load4(fr, cur);
 #pragma unroll
-  for (int i = 0; i < 4; ++i) fb[i] = qkf_ldg(bp + i * bstep, boff), fx[i] = qkf_ldx(xp + i * xstep, xoff);
-  const int nfull = nks >> 2, tail = nks & 3, ng = (nks + 3) >> 2;
+  for (int i = 0; i < 4; ++i) fx[i] = qkf_ldx(xp + i * xstep, xoff);
+  const int ng = (nks + 3) >> 2, last = nks - 4 * (ng - 1);  // k-steps of the last group: 1..4
 #pragma unroll 1
-  for (int gq = 0; gq < nfull; ++gq) {
-    const int adv = (gq + 1 < ng) ? 4 : 0;
-    boff += adv * bstep, xoff += adv * xstep;
+  for (int gq = 0; gq + 1 < ng; ++gq) {
+    cur.off += 4 * cur.step, xoff += 4 * xstep;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      qkf_kstep<false>(p1, p2, p3, fx[i].x, fx[i].y, fb[i].x, fb[i].y);
-      fb[i] = qkf_ldg(bp + i * bstep, boff), fx[i] = qkf_ldx(xp + i * xstep, xoff);
+      qkf_kstep<false>(p1, p2, p3, fx[i].x, fx[i].y, fr[i].x, fr[i].y);
+      fr[i] = qkf_ldg(cur.base + i * cur.step, cur.off), fx[i] = qkf_ldx(xp + i * xstep, xoff);
       __builtin_amdgcn_sched_barrier(0);
     }
   }
 #pragma unroll
-  for (int i = 0; i < 3; ++i)
-    if (i < tail) qkf_kstep<false>(p1, p2, p3, fx[i].x, fx[i].y, fb[i].x, fb[i].y);
+  for (int i = 0; i < 4; ++i) {
+    if (i < last) qkf_kstep<false>(p1, p2, p3, fx[i].x, fx[i].y, fr[i].x, fr[i].y);
+    fr[i] = qkf_ldg(nxt.base + i * nxt.step, nxt.off);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  t.re = p1 - p2;
+  t.im = p3 - p1 - p2;
 }
 
-// Phase 2, one item: X'[tb rows, tn cols] += sum_p T_p^T conj(A[16 ta + ., p, 16 tn + .]) for every tn, accumulated
-// into the LDS image `xo` (row stride a2, this item's 16 rows start at xo).  A operand element of k-step i, block p,
-// column block tn: ap + aoff + (p + 8 i) a2 + 16 tn, aoff = this lane's ((16 ta + q) * 2) * a2 + j.  FULL: all four k-steps
-// of this ta block lie below the true bond (every block but the last one of a ragged bond); otherwise kmax of them do.
+// Phase 2, one item: X'[tb rows, tn cols] += T^T conj(A[16 ta + ., p, 16 tn + .]) for every column block tn, added into
+// the LDS image `xo` (row stride a2, this item's 16 rows start at xo) with ds_add_f64.  A operand: stream `cur` (group
+// = column block tn: off advances by 16 per group; step = one k-step = 4 rows of a).  FULL: all four k-steps of this ta
+// block lie below the true bond (every block but the last one of a ragged bond); otherwise kmax of them do.  The last
+// group reloads the registers with the first group of `nxt` (the wave's next item, or its first tile of the next site).
 template <bool FULL>
-__device__ __forceinline__ void qkf_p2_item(const QkfTile& t0, const QkfTile& t1, const v2d* __restrict__ ap, unsigned aoff, const int a2, const int nn, const int kmax,
-                                            lds_v2d* xo, const int q, const int j) {
-  v2d fa[4];
-  const int kstep = 8 * a2;  // elements per k-step: 4 rows of a, 2 p each
-#pragma unroll
-  for (int i = 0; i < 4; ++i) fa[i] = qkf_ldg(ap + i * kstep, aoff);
+__device__ __forceinline__ void qkf_p2_item(const QkfTile& t, v2d (&fr)[4], const bool primed, QkfStream cur, const int a2, const int nn, const int kmax, lds_v2d* xo, const int q,
+                                            const int j, const QkfStream nxt) {
+  if (!primed) qkf_load4(fr, cur);
   __attribute__((address_space(3))) double* d = (__attribute__((address_space(3))) double*)(xo + q * a2 + j);
 #pragma unroll 1
   for (int tn = 0; tn < nn; ++tn) {
     v4d p1 = {0, 0, 0, 0}, p2 = {0, 0, 0, 0}, p3 = {0, 0, 0, 0};
+    const bool fin = tn + 1 == nn;
+    const v2d* const rb = fin ? nxt.base : cur.base;
+    const int rs = fin ? nxt.step : cur.step;
+    cur.off = fin ? nxt.off : cur.off + TILE;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {  // p = 0; the registers of a k-step are reloaded for p = 1 right after its MFMAs
-      if (FULL || i < kmax) qkf_kstep<true>(p1, p2, p3, t0.re[i], t0.im[i], fa[i].x, fa[i].y);
-      fa[i] = qkf_ldg(ap + a2 + i * kstep, aoff);
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    aoff += (tn + 1 < nn) ? TILE : 0;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {  // p = 1; reloaded for p = 0 of the next tn
-      if (FULL || i < kmax) qkf_kstep<true>(p1, p2, p3, t1.re[i], t1.im[i], fa[i].x, fa[i].y);
-      fa[i] = qkf_ldg(ap + i * kstep, aoff);
+    for (int i = 0; i < 4; ++i) {
+      if (FULL || i < kmax) qkf_kstep<true>(p1, p2, p3, t.re[i], t.im[i], fr[i].x, fr[i].y);
+      fr[i] = qkf_ldg(rb + i * rs, cur.off);
       __builtin_amdgcn_sched_barrier(0);
     }
     const v4d re = p1 + p2, im = p3 - p1 + p2;
@@ -133,21 +149,33 @@ __device__ __forceinline__ void qkf_p2_item(const QkfTile& t0, const QkfTile& t1
   }
 }
 
-// The T tiles of a wave live in registers, S slots of two tiles.  The slot loops are NOT unrolled (unrolled, every slot
-// drags ~50 VGPRs of hoisted address state through the whole sweep) and the working slot is always T[S-1]: when a
-// phase has more items than waves the array is rotated by one slot before each item (phase 1 makes all S turns, so
-// that item s ends in slot s; phase 2 turns once per item, which brings item s to slot S-1).
+// The T tiles of a wave live in registers, S slots.  The slot loops are NOT unrolled (unrolled, every slot drags ~50
+// VGPRs of hoisted address state through the whole sweep) and the working slot is always T[S-1]: when a phase has more
+// items than waves the array is rotated by one slot before each item (phase 1 makes all S turns, so that item s ends
+// in slot s; phase 2 turns once per item, which brings item s to slot S-1).
 template <int S>
-__device__ __forceinline__ void qkf_rotate(QkfTile (&T)[S][2]) {
-  const QkfTile t0 = T[0][0], t1 = T[0][1];
+__device__ __forceinline__ void qkf_rotate(QkfTile (&T)[S]) {
+#ifdef QKF_EXP_NOROT
+  return;
+#endif
+  const QkfTile t0 = T[0];
 #pragma unroll
-  for (int e = 0; e + 1 < S; ++e) T[e][0] = T[e + 1][0], T[e][1] = T[e + 1][1];
-  T[S - 1][0] = t0, T[S - 1][1] = t1;
+  for (int e = 0; e + 1 < S; ++e) T[e] = T[e + 1];
+  T[S - 1] = t0;
 }
 
-template <int NW, int S>  // waves per workgroup, T slots per wave: a phase holds up to NW * S items
+// What a site needs: bonds, tile counts, where its X / X' live and how its items are cut into strips.
+struct QkfSite {
+  int a, a2, b, b2, at, nks, mt, nt, nn, W, inv;  // inv = ceil(2^20 / mt): u / mt == (u * inv) >> 20 for u < 2048, mt <= 32 (checked exhaustively)
+  bool small;
+  const v2d *Ak, *Bk;
+};
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) v4i lds_v4i;
+
+template <int NW, int S, int XCAP>  // waves per workgroup; T slots per wave (a round holds NW * S items); elements of the LDS X buffer
 __global__ __launch_bounds__(64 * NW, 2) void qk_sweep_fused_kernel(const SweepArgs g) {
-  constexpr int XCAP = QKF_XCAP, NT = 64 * NW;
+  constexpr int NT = 64 * NW;
   extern __shared__ __attribute__((aligned(16))) double lds_raw[];
   lds_v2d* const XL = (lds_v2d*)lds_raw;  // (a C-style cast: the generic -> LDS address-space cast)
   long long* const slot = reinterpret_cast<long long*>(lds_raw + 2 * XCAP);
@@ -158,53 +186,46 @@ __global__ __launch_bounds__(64 * NW, 2) void qk_sweep_fused_kernel(const SweepA
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int j = lane & 15, q = lane >> 4;
   const int ns = g.n_sites, n1 = ns + 1;
-  int* const m_xd = reinterpret_cast<int*>(slot + 2);
-  int* const m_yd = m_xd + n1;
-  int* const m_xt = m_yd + n1;
-  int* const m_yt = m_xt + n1;
-  long long* const m_xo = reinterpret_cast<long long*>(m_xd + 4 * n1 + (4 * n1 & 1));
-  long long* const m_yo = m_xo + ns;
-  auto ldi = [&](const int* p_) __attribute__((always_inline)) { return __builtin_amdgcn_readfirstlane(*p_); };
+  // per-site records of the current pair, built by all threads at pair set-up: 12 ints (48 bytes) per site
+  //   [0] a  [1] a2  [2] b  [3] b2  [4] true a  [5] k-steps of b  [6] W  [7] small  [8] ceil(2^20 / mt)  [9] -  [10..11] -
+  // and the two tensor offsets (elements of the interleaved image) as int64 in a second table
+  lds_v4i* const rec = (lds_v4i*)(slot + 2);
+  long long* const m_off = reinterpret_cast<long long*>(slot + 2) + 6 * (long long)ns;  // [ns][2]: A_k, B_k
+  auto rfl = [&](const int v) __attribute__((always_inline)) { return __builtin_amdgcn_readfirstlane(v); };
   auto ldl = [&](const long long* p_) __attribute__((always_inline)) {
     const long long v = *p_;
     const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v);
     const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)((unsigned long long)v >> 32));
     return (long long)(((unsigned long long)hi << 32) | lo);
   };
-#ifndef QKF_TOUCH_DIST
-#define QKF_TOUCH_DIST 2
-#endif
-  // Touch-ahead: every pair streams its two states from HBM exactly once, and a wave keeps only four fragment loads in
-  // flight -- far too few bytes to cover an HBM miss.  So the waves that finish a site early (fewer items than the
-  // others, or none) read one word of every 128-byte line of the tensors of site k + QKF_TOUCH_DIST while they would
-  // otherwise wait at the site's last barrier: 8 KiB in flight per load instruction, and the fragments of that site
-  // are then L2 / Infinity-Cache hits.  The words are folded into `sink`, which is never stored.
-  unsigned sink = 0;
-  auto touch = [&](const int kk, const int items_here) __attribute__((always_inline)) {
-    if (kk >= ns) return;
-    const int first = (items_here >= NW) ? items_here % NW : items_here;  // waves first .. NW-1 carry the lighter load
-    if (wave < first) return;
-    const unsigned stride = (unsigned)(NW - first) * 64u * 32u, o0 = ((unsigned)(wave - first) * 64u + lane) * 32u;
-    const unsigned* An = reinterpret_cast<const unsigned*>(xdata + (ldl(m_xo + kk) >> 1));
-    const unsigned* Bn = reinterpret_cast<const unsigned*>(ydata + (ldl(m_yo + kk) >> 1));
-    const unsigned nA = (unsigned)(ldi(m_xd + kk) * 2 * ldi(m_xd + kk + 1)) * 4u, nB = (unsigned)(ldi(m_yd + kk) * 2 * ldi(m_yd + kk + 1)) * 4u;  // dwords
-    for (unsigned o = o0; o < nA; o += 4 * stride) {
-      const unsigned u0 = An[o], u1 = (o + stride < nA) ? An[o + stride] : 0u, u2 = (o + 2 * stride < nA) ? An[o + 2 * stride] : 0u, u3 = (o + 3 * stride < nA) ? An[o + 3 * stride] : 0u;
-      sink ^= u0 ^ u1 ^ u2 ^ u3;
-    }
-    for (unsigned o = o0; o < nB; o += 4 * stride) {
-      const unsigned u0 = Bn[o], u1 = (o + stride < nB) ? Bn[o + stride] : 0u, u2 = (o + 2 * stride < nB) ? Bn[o + 2 * stride] : 0u, u3 = (o + 3 * stride < nB) ? Bn[o + 3 * stride] : 0u;
-      sink ^= u0 ^ u1 ^ u2 ^ u3;
-    }
+  auto site = [&](const int k) __attribute__((always_inline)) {
+    const v4i r0 = rec[3 * k], r1 = rec[3 * k + 1], r2 = rec[3 * k + 2];  // every lane reads the same 48 bytes
+    QkfSite s;
+    s.a = rfl(r0.x), s.a2 = rfl(r0.y), s.b = rfl(r0.z), s.b2 = rfl(r0.w);
+    s.at = rfl(r1.x), s.nks = rfl(r1.y), s.W = rfl(r1.z), s.small = rfl(r1.w) != 0;
+    s.inv = rfl(r2.x);
+    s.mt = s.a / TILE, s.nt = s.b2 / TILE, s.nn = s.a2 / TILE;
+    s.Ak = xdata + ldl(m_off + 2 * k);      // [a][2][a2]
+    s.Bk = ydata + ldl(m_off + 2 * k + 1);  // [b][2][b2]
+    return s;
+  };
+  // the streams of item `it` of a strip starting at block s0 (it = 2 (tbl * mt + ta) + p)
+  auto b_stream = [&](const QkfSite& s, const int s0, const int it) __attribute__((always_inline)) {
+    const int pp = it & 1, u = it >> 1, tbl = (u * s.inv) >> 20;
+    return QkfStream{s.Bk + pp * s.b2, (unsigned)((q * 2) * s.b2 + (s0 + tbl) * TILE + j), 8 * s.b2};
+  };
+  auto a_stream = [&](const QkfSite& s, const int it) __attribute__((always_inline)) {
+    const int pp = it & 1, u = it >> 1, tbl = (u * s.inv) >> 20, ta = u - tbl * s.mt;
+    return QkfStream{s.Ak + pp * s.a2, (unsigned)(((ta * TILE + q) * 2) * s.a2 + j), 8 * s.a2};
   };
 #ifdef QKF_PROF  // experiment builds only: cycle sums per section of a wave's life (tools/fused_sections.py)
   unsigned long long pf[8] = {0, 0, 0, 0, 0, 0, 0, 0}, pt = __builtin_amdgcn_s_memtime();
   const unsigned long long pt0 = pt;
-#define QKF_STAMP(i)                                          \
-  do {                                                        \
+#define QKF_STAMP(i)                                              \
+  do {                                                            \
     const unsigned long long now_ = __builtin_amdgcn_s_memtime(); \
-    pf[i] += now_ - pt;                                       \
-    pt = now_;                                                \
+    pf[i] += now_ - pt;                                           \
+    pt = now_;                                                    \
   } while (0)
 #else
 #define QKF_STAMP(i)
@@ -216,106 +237,114 @@ __global__ __launch_bounds__(64 * NW, 2) void qk_sweep_fused_kernel(const SweepA
     __syncthreads();
     if (p >= g.npairs) break;
     const int xi = g.pairs[2 * p], yj = g.pairs[2 * p + 1];
-    for (int e = tid; e < n1; e += NT) {
-      m_xd[e] = g.xdims[(long long)xi * n1 + e];
-      m_yd[e] = g.ydims[(long long)yj * n1 + e];
-      m_xt[e] = g.xtrue[(long long)xi * n1 + e];
-      m_yt[e] = g.ytrue[(long long)yj * n1 + e];
-      if (e < ns) {
-        m_xo[e] = g.xoffs[(long long)xi * ns + e];
-        m_yo[e] = g.yoffs[(long long)yj * ns + e];
-      }
+    for (int e = tid; e < ns; e += NT) {  // site e of the pair
+      const int a = g.xdims[(long long)xi * n1 + e], a2 = g.xdims[(long long)xi * n1 + e + 1];
+      const int b = g.ydims[(long long)yj * n1 + e], b2 = g.ydims[(long long)yj * n1 + e + 1];
+      const int mt = a / TILE, nt = b2 / TILE;
+      // an item is (ta, tb, p): 2 mt nt of them.  LDS-resident site: X and X' fit the buffer and ONE round holds all items;
+      // otherwise X' is built in strips of W blocks of b' (the strip's rows must fit the LDS), items in rounds of NW * S
+      const int small = a * b <= XCAP && a2 * b2 <= XCAP && 2 * mt * nt <= NW * S;
+      const int W = small ? nt : max(1, min(nt, XCAP / (TILE * a2)));
+      rec[3 * e] = (v4i){a, a2, b, b2};
+      rec[3 * e + 1] = (v4i){g.xtrue[(long long)xi * n1 + e], (g.ytrue[(long long)yj * n1 + e] + 3) >> 2, W, small};
+      rec[3 * e + 2] = (v4i){((1 << 20) + mt - 1) / mt, 0, 0, 0};
+      m_off[2 * e] = g.xoffs[(long long)xi * ns + e] >> 1;
+      m_off[2 * e + 1] = g.yoffs[(long long)yj * ns + e] >> 1;
     }
     for (int e = tid; e < TILE * TILE; e += NT) XL[e] = (v2d){e == 0 ? 1.0 : 0.0, 0.0};  // X_0 = 1 in a 16 x 16 block
     __syncthreads();
     QKF_STAMP(0);  // pair set-up
-    bool xg = false;  // where X lives: LDS (row stride a) or the global buffer G0 + cur * x_plane
-    int cur = 0;
-    QkfTile T[S][2];
+    bool xg = false;  // where X lives: LDS (at element xb, row stride a) or the global buffer G0 + cur * x_plane
+    int cur = 0, xb = 0;
+    QkfTile T[S];
+    v2d fr[4];            // the fragment registers of the wave's global stream: they carry its next group across tiles and barriers
+    bool primed = false;  // fr holds the first group of the wave's next tile
+    QkfSite sn = site(0);
     for (int k = 0; k < ns; ++k) {
-      const int a = ldi(m_xd + k), a2 = ldi(m_xd + k + 1), b = ldi(m_yd + k), b2 = ldi(m_yd + k + 1);
-      const int at = ldi(m_xt + k), bt = ldi(m_yt + k);
-      const int mt = a / TILE, nt = b2 / TILE, nn = a2 / TILE;
-      const int nks = (bt + 3) >> 2;
-      const v2d* const Ak = xdata + (ldl(m_xo + k) >> 1);  // [a][2][a2]
-      const v2d* const Bk = ydata + (ldl(m_yo + k) >> 1);  // [b][2][b2]
-      const bool small = a * b <= XCAP && a2 * b2 <= XCAP && mt * nt <= NW * S;
+      const QkfSite sc = sn;
+      if (k + 1 < ns) sn = site(k + 1);
+      const int a = sc.a, a2 = sc.a2, b = sc.b, mt = sc.mt, nt = sc.nt, W = sc.W;
+      const bool small = sc.small;
       v2d* const Gc = G0 + (long long)cur * g.x_plane;
       v2d* const Gn = G0 + (long long)(cur ^ 1) * g.x_plane;
       // ---- where X has to be for this site
       if (small && xg) {  // global -> LDS
         for (int e = tid; e < a * b; e += NT) XL[e] = Gc[e];
         __syncthreads();
-        xg = false;
+        xg = false, xb = 0;
       } else if (!small && !xg) {  // LDS -> global (the LDS is needed for the strips of X')
-        for (int e = tid; e < a * b; e += NT) Gc[e] = XL[e];
+        for (int e = tid; e < a * b; e += NT) Gc[e] = XL[xb + e];
         __syncthreads();
         xg = true;
       }
-      QKF_STAMP(1);  // X moved between LDS and the global buffer
-      // strip width (blocks of b'): the strip's rows of X' must fit the LDS; its items run in rounds of NW * S (the T registers)
-#ifdef QKF_OLD_W
-      const int W = small ? nt : max(1, min(nt, min((NW * S) / mt, XCAP / (TILE * a2))));
-#else
-      const int W = small ? nt : max(1, min(nt, XCAP / (TILE * a2)));
+      // LDS-resident site: when X and X' fit the buffer side by side, X' goes to the other end and is zeroed right here
+      // (that region held the X of the previous site, dead since its last barrier): one barrier between the phases
+      // instead of barrier - zero - barrier.  Otherwise X' overwrites X from element 0.
+      const int n_out = sc.b2 * a2;
+      const bool pingpong = small && a * b + n_out <= XCAP;
+      const int ob = !small ? 0 : pingpong ? (xb == 0 ? XCAP - n_out : 0) : 0;  // where X' (or the strip of X') is built
+#ifndef QKF_EXP_NOZERO
+      if (pingpong)
+        for (int e = tid; e < n_out; e += NT) XL[ob + e] = (v2d){0.0, 0.0};
 #endif
+      QKF_STAMP(1);  // X moved between LDS and the global buffer
       for (int s0 = 0; s0 < nt; s0 += W) {
-        const int w = min(W, nt - s0), items = mt * w;
-        if (!small) {  // zero this strip's X' rows (the small path zeroes after phase 1: X is still being read)
+        const int w = min(W, nt - s0), items = 2 * mt * w;
+        if (!small) {  // zero this strip's X' rows (the LDS-resident path zeroes after phase 1: X is still being read)
           for (int e = tid; e < w * TILE * a2; e += NT) XL[e] = (v2d){0.0, 0.0};
           qk_lds_barrier();
         }
-        QKF_STAMP(6);  // strip zeroing, touch-ahead
-        for (int r0 = 0; r0 < items; r0 += NW * S) {  // (one round on the small path)
-          // ---- phase 1: T tiles of this wave's items
+        QKF_STAMP(6);  // strip zeroing
+        for (int r0 = 0; r0 < items; r0 += NW * S) {  // (one round on the LDS-resident path)
           const bool multi = items - r0 > NW;  // more than one slot in use
+          const int it0 = r0 + wave;          // this wave's items: it0, it0 + NW, ...
+          // ---- phase 1: the T tile of each of this wave's items
           auto phase1 = [&](auto xbase) __attribute__((always_inline)) {
 #pragma unroll 1
             for (int s = 0; s < (multi ? S : 1); ++s) {
               if (multi) qkf_rotate<S>(T);
-              const int it = r0 + wave + NW * s;
+              const int it = it0 + NW * s;
               if (it < items) {
-                const int tbl = it / mt, ta = it - tbl * mt;
-                const unsigned boff = (unsigned)((q * 2) * b2 + (s0 + tbl) * TILE + j), xoff = (unsigned)(q * a + ta * TILE + j);
-#pragma unroll 1
-                for (int pp = 0; pp < 2; ++pp) {
-                  v4d p1, p2, p3;
-                  qkf_p1_tile(p1, p2, p3, Bk + pp * b2, boff, 8 * b2, xbase, xoff, 4 * a, nks);
-                  if (pp == 0) T[S - 1][0].re = p1 - p2, T[S - 1][0].im = p3 - p1 - p2;
-                  else T[S - 1][1].re = p1 - p2, T[S - 1][1].im = p3 - p1 - p2;
-                }
+                const int u = it >> 1, tbl = (u * sc.inv) >> 20, ta = u - tbl * mt;
+                const bool more = s + 1 < S && it + NW < items;  // another tile follows in this phase; else phase 2 starts with item it0
+                const QkfStream nxt = more ? b_stream(sc, s0, it + NW) : a_stream(sc, it0);
+                qkf_p1_tile(T[S - 1], fr, primed, b_stream(sc, s0, it), xbase, (unsigned)(q * a + ta * TILE + j), 4 * a, sc.nks, nxt);
+                primed = true;
               }
             }
           };
           if (xg) phase1((const v2d*)Gc);
-          else phase1((const lds_v2d*)XL);
+          else phase1((const lds_v2d*)(XL + xb));
           QKF_STAMP(2);  // phase 1
           if (small) {
-            qk_lds_barrier();  // every wave has read X: it becomes X'
-            for (int e = tid; e < b2 * a2; e += NT) XL[e] = (v2d){0.0, 0.0};
-            qk_lds_barrier();
+            qk_lds_barrier();  // ping-pong: X' is zero everywhere; in place: every wave has read X, it becomes X'
+            if (!pingpong) {
+              for (int e = tid; e < n_out; e += NT) XL[e] = (v2d){0.0, 0.0};
+              qk_lds_barrier();
+            }
           }
           QKF_STAMP(3);  // wait for the other waves' phase 1, zero X'
-          // ---- phase 2: accumulate the items' contributions to X'[strip rows]
+          // ---- phase 2: add the items' contributions to X'[strip rows]
+          const bool last_round = s0 + W >= nt && r0 + NW * S >= items;
 #pragma unroll 1
           for (int s = 0; s < S; ++s) {
-            const int it = r0 + wave + NW * s;
+            const int it = it0 + NW * s;
             if (it >= items) break;
             if (multi) qkf_rotate<S>(T);
-            const int tbl = it / mt, ta = it - tbl * mt;
-            const int kmax = min(4, (at - ta * TILE + 3) >> 2);
-            const unsigned aoff = (unsigned)(((ta * TILE + q) * 2) * a2 + j);
-            if (kmax == 4) qkf_p2_item<true>(T[S - 1][0], T[S - 1][1], Ak, aoff, a2, nn, 4, XL + tbl * TILE * a2, q, j);
-            else qkf_p2_item<false>(T[S - 1][0], T[S - 1][1], Ak, aoff, a2, nn, kmax, XL + tbl * TILE * a2, q, j);
+            const int u = it >> 1, tbl = (u * sc.inv) >> 20, ta = u - tbl * mt;
+            const int kmax = min(4, (sc.at - ta * TILE + 3) >> 2);
+            const bool more = s + 1 < S && it + NW < items;
+            // after the wave's last item of the site: its first tile of the next site (strip 0, round 0), if it has one
+            const bool chain = !more && last_round && k + 1 < ns && wave < 2 * sn.mt * min(sn.W, sn.nt);
+            const QkfStream nxt = more ? a_stream(sc, it + NW) : chain ? b_stream(sn, 0, wave) : a_stream(sc, it);
+            if (kmax == 4) qkf_p2_item<true>(T[S - 1], fr, primed, a_stream(sc, it), a2, sc.nn, 4, XL + ob + tbl * TILE * a2, q, j, nxt);
+            else qkf_p2_item<false>(T[S - 1], fr, primed, a_stream(sc, it), a2, sc.nn, kmax, XL + ob + tbl * TILE * a2, q, j, nxt);
+            primed = more || chain;
           }
           QKF_STAMP(4);  // phase 2
         }
-#ifdef QKF_TOUCH
-        if (s0 + W >= nt) touch(k + QKF_TOUCH_DIST, mt * nt);
-#endif
-        QKF_STAMP(6);
         qk_lds_barrier();  // the strip of X' is complete
-        QKF_STAMP(5);  // wait for the other waves' phase 2
+        QKF_STAMP(5);      // wait for the other waves' phase 2
         if (!small && nt > W) {  // several strips: this one goes to the other global buffer
           for (int e = tid; e < w * TILE * a2; e += NT) Gn[(long long)s0 * TILE * a2 + e] = XL[e];
           __syncthreads();
@@ -323,12 +352,14 @@ __global__ __launch_bounds__(64 * NW, 2) void qk_sweep_fused_kernel(const SweepA
         }
       }
       if (!small) {
-        if (nt > W) cur ^= 1;  // X' was written strip by strip to Gn
-        else xg = false;       // a single strip: X' is complete in LDS
+        if (nt > W) cur ^= 1;      // X' was written strip by strip to Gn
+        else xg = false, xb = 0;   // a single strip: X' is complete in LDS
+      } else {
+        xb = ob;
       }
     }
     if (tid == 0) {
-      const v2d zz = xg ? G0[(long long)cur * g.x_plane] : (v2d)XL[0];
+      const v2d zz = xg ? G0[(long long)cur * g.x_plane] : (v2d)XL[xb];
       g.values[p] = zz.x * zz.x + zz.y * zz.y;
       if (g.z) {
         g.z[2 * p] = zz.x;
@@ -337,7 +368,6 @@ __global__ __launch_bounds__(64 * NW, 2) void qk_sweep_fused_kernel(const SweepA
     }
     __syncthreads();
   }
-  if (sink == 0x5a5a5a5au && g.npairs < 0) g.values[0] = 0.0;  // never true: keeps the touch-ahead loads alive
 #ifdef QKF_PROF
   if (lane == 0) {
     pf[7] = __builtin_amdgcn_s_memtime() - pt0;

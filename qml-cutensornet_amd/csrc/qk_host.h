@@ -35,6 +35,7 @@ struct qk_ctx {
   int wgs_per_cu = 2;  // resident workgroups per CU (QK_WGS_PER_CU)
   bool wave_path = true;   // fp64 sets whose bonds are all <= 16 use the one-wave-per-pair register sweep (QK_WAVE=0 opts out)
   bool small_path = true;  // sets whose bonds are all <= 32 use the LDS-resident small-bond sweep (QK_SMALL=0 opts out)
+  int fused_wgs = 0;       // workgroups per CU of the site-fused sweep: 0 = chosen per launch from the plan, 1 / 2 forced (QK_FUSED_WGS)
   int fused_path = 1;      // fp64 sets with a bond > 32 use the site-fused sweep (QK_FUSED=0: ring sweep instead; 2: also for bonds 17..32)
   qk_stats last{};
 };
@@ -62,6 +63,7 @@ struct qk_plan {
   std::vector<int32_t> groups;  // (first pair, count): runs of <= group pairs that share the x state
   int group = 1;
   qk_stats stats{};
+  double fit_two = 1.0;  // share of this rank's padded work in sites whose X and X' fit the fused sweep's smaller LDS buffer
   // lazily uploaded copy
   qk_ctx* up_ctx = nullptr;
   int32_t* d_pairs = nullptr;

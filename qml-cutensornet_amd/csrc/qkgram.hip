@@ -92,8 +92,9 @@ extern "C" int qk_pack_state(int32_t n_sites, const int32_t* bond_dims, const do
 // ----------------------------------------------------------------------------------------
 // Algorithmic flops of one overlap: 8 real flops per complex
 // multiply-add, cheaper association per site.  Padded: what this engine executes.
-static void pair_work(int n, const int32_t* a, const int32_t* b, double* flops, double* padded, double* bytes) {
-  double f = 0, fp = 0, by = 0;
+static constexpr int QKF_XCAP_ONE = 8192, QKF_XCAP_TWO = 4608;  // elements of the fused sweep's LDS X buffer with one / two workgroups per CU
+static void pair_work(int n, const int32_t* a, const int32_t* b, double* flops, double* padded, double* bytes, double* fit_two = nullptr) {
+  double f = 0, fp = 0, by = 0, ft = 0;
   for (int k = 0; k < n; ++k) {
     const double a0 = a[k], a1 = a[k + 1], b0 = b[k], b1 = b[k + 1];
     const double f1 = a0 * b0 * 2 * b1 + 2 * a0 * a1 * b1;
@@ -101,8 +102,10 @@ static void pair_work(int n, const int32_t* a, const int32_t* b, double* flops, 
     f += 8 * std::min(f1, f2);
     const double A0 = pad16(a[k]), A1 = pad16(a[k + 1]), B0 = pad16(b[k]), B1 = pad16(b[k + 1]);
     fp += 8 * (A0 * B0 * 2 * B1 + 2 * A0 * A1 * B1);
+    if (A0 * B0 <= QKF_XCAP_TWO && A1 * B1 <= QKF_XCAP_TWO) ft += 8 * (A0 * B0 * 2 * B1 + 2 * A0 * A1 * B1);  // X and X' of this site fit the smaller buffer
     by += 16.0 * 2 * (a0 * a1 + b0 * b1);
   }
+  if (fit_two) *fit_two = ft;
   *flops = f;
   *padded = fp;
   *bytes = by + 8;
@@ -189,7 +192,7 @@ extern "C" int qk_plan_create(int32_t n_sites, int32_t nx, const int32_t* x_dims
   const int stride = n_sites + 1;
   int64_t t = 0;  // running index in the global order
   std::vector<int64_t> per_rank(world_size, 0);
-  double flops = 0, padded = 0, bytes = 0;
+  double flops = 0, padded = 0, bytes = 0, fit_two = 0;
   const int nbx = (nx + block - 1) / block, nby = (ny + block - 1) / block;
   for (int bj = 0; bj < nby; ++bj)
     for (int bi = 0; bi < nbx; ++bi) {
@@ -212,9 +215,9 @@ extern "C" int qk_plan_create(int32_t n_sites, int32_t nx, const int32_t* x_dims
         if (r == rank) {
           p->pairs.push_back(it.i);
           p->pairs.push_back(it.j);
-          double f, fp, by;
-          pair_work(n_sites, x_dims + (int64_t)it.i * stride, y_dims + (int64_t)it.j * stride, &f, &fp, &by);
-          flops += f, padded += fp, bytes += by;
+          double f, fp, by, ft;
+          pair_work(n_sites, x_dims + (int64_t)it.i * stride, y_dims + (int64_t)it.j * stride, &f, &fp, &by, &ft);
+          flops += f, padded += fp, bytes += by, fit_two += ft;
         }
         ++t;
       }
@@ -264,6 +267,7 @@ extern "C" int qk_plan_create(int32_t n_sites, int32_t nx, const int32_t* x_dims
   p->max_per_rank = *std::max_element(per_rank.begin(), per_rank.end());
   p->stats.pairs = (int64_t)p->pairs.size() / 2;
   p->stats.flops = flops, p->stats.padded_flops = padded, p->stats.bytes = bytes;
+  p->fit_two = padded > 0 ? fit_two / padded : 1.0;
   *out = p;
   return QK_OK;
 }
@@ -355,7 +359,8 @@ extern "C" int qk_ctx_create(int device_id, qk_ctx** out) {
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(qk_sweep_ring_kernel<double>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(qk_sweep_small_kernel<double>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(qk_sweep_small_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
-  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(qk_sweep_fused_kernel<QKF_NW, QKF_SLOTS>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(qk_sweep_fused_kernel<8, QKF_SLOTS, QKF_XCAP_ONE>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(qk_sweep_fused_kernel<4, QKF_SLOTS, QKF_XCAP_TWO>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
   {
     const int rc = qk_lab_init(c);
     if (rc != QK_OK) return rc;
@@ -364,6 +369,7 @@ extern "C" int qk_ctx_create(int device_id, qk_ctx** out) {
   if (const char* v = std::getenv("QK_SMALL")) c->small_path = std::atoi(v) != 0;
   if (const char* v = std::getenv("QK_WAVE")) c->wave_path = std::atoi(v) != 0;
   if (const char* v = std::getenv("QK_FUSED")) c->fused_path = std::atoi(v);
+  if (const char* v = std::getenv("QK_FUSED_WGS")) c->fused_wgs = std::max(0, std::min(2, std::atoi(v)));
   if (const char* v = std::getenv("QK_WGS_PER_CU")) c->wgs_per_cu = std::max(1, std::min(4, std::atoi(v)));
   *out = c;
   return QK_OK;
@@ -576,11 +582,17 @@ extern "C" int qk_gram_values(qk_ctx* c, const qk_mps_set* xs, const qk_mps_set*
   const long long t_plane = 2 * x_plane;
   const long long units = quad ? np / 4 : grouped ? (long long)plan->groups.size() / 2 : (duo ? (np + 1) / 2 : np);
   const int max_pad = std::max(xs->max_pad, ys->max_pad);
-  // the site-fused sweep (qk_fused.h): fp64, one workgroup per CU; bonds up to XCAP / 16 = 512 (one 16-row strip of X' must fit the LDS)
-  const size_t lds_fused = (size_t)QKF_XCAP * 16 + 16 + (size_t)(4 * (xs->n_sites + 1) + 2) * sizeof(int) + (size_t)2 * xs->n_sites * sizeof(long long);
-  const bool fused = c->variant == 20 && !f32 && !quad && c->fused_path != 0 && max_pad > (c->fused_path >= 2 ? 16 : 32) &&
-                     max_pad <= QKF_XCAP / TILE && lds_fused <= (size_t)160 * 1024 / (8 / QKF_NW);
-  const int grid = (int)std::min<long long>(units, (long long)(fused ? 8 / QKF_NW : c->wgs_per_cu) * c->num_cus);  // the fused sweep: 8 waves per CU
+  // the site-fused sweep (qk_fused.h), fp64.  Two shapes: one 8-wave workgroup per CU with an 8192-element X buffer, or two
+  // 4-wave workgroups with 4608 elements each (better when most of the work sits in sites that fit the smaller buffer: the
+  // second workgroup fills the first one's barriers).  A 16-row strip of X' must fit the buffer: bonds <= XCAP / 16.
+  const size_t lds_meta = 16 + (size_t)xs->n_sites * (48 + 16);  // queue slot, per-site records and tensor offsets
+  const bool fused_ok = c->variant == 20 && !f32 && !quad && c->fused_path != 0 && max_pad > (c->fused_path >= 2 ? 16 : 32);
+  const bool can_one = max_pad <= QKF_XCAP_ONE / TILE && (size_t)QKF_XCAP_ONE * 16 + lds_meta <= 160 * 1024;
+  const bool can_two = max_pad <= QKF_XCAP_TWO / TILE && (size_t)QKF_XCAP_TWO * 16 + lds_meta <= 80 * 1024;
+  const bool fused = fused_ok && (can_one || can_two);
+  const bool fused_two = fused && can_two && (!can_one || c->fused_wgs == 2 || (c->fused_wgs == 0 && plan->fit_two >= 0.4));
+  const size_t lds_fused = (size_t)(fused_two ? QKF_XCAP_TWO : QKF_XCAP_ONE) * 16 + lds_meta;
+  const int grid = (int)std::min<long long>(units, (long long)(fused ? (fused_two ? 2 : 1) : c->wgs_per_cu) * c->num_cus);
   const size_t need = (size_t)grid * (size_t)chains * 2 * (size_t)(x_plane + t_plane) * sizeof(double);
   if (need > c->scratch_bytes) {
     HIP_TRY(hipStreamSynchronize(c->stream));
@@ -618,7 +630,7 @@ extern "C" int qk_gram_values(qk_ctx* c, const qk_mps_set* xs, const qk_mps_set*
     const int wgrid = (int)std::min<long long>(np, 16ll * c->num_cus);
     qk_sweep_wave_kernel<0><<<dim3(wgrid), dim3(64), 0, c->stream>>>(a);
     c->last.grid = wgrid;
-  } else if (c->variant == 20 && c->small_path && std::max(xs->max_pad, ys->max_pad) <= 32 && lds_small <= 80 * 1024) {
+  } else if (!fused && c->variant == 20 && c->small_path && std::max(xs->max_pad, ys->max_pad) <= 32 && lds_small <= 80 * 1024) {
     // every bond <= 32: X and T stay in LDS, only the site tensors stream (qk_sweep_small_kernel); chains too long for
     // its LDS budget (several hundred sites) take the ring kernel below
     if (f32) qk_sweep_small_kernel<float><<<dim3(grid), dim3(512), lds_small, c->stream>>>(a);
@@ -632,7 +644,8 @@ extern "C" int qk_gram_values(qk_ctx* c, const qk_mps_set* xs, const qk_mps_set*
     a.xdata = xs->d_il, a.ydata = ys->d_il;
     a.x_plane = (long long)xs->max_pad * ys->max_pad;  // complex elements per global X buffer (two per workgroup)
     HIP_TRY(hipEventRecord(c->ev0, c->stream));        // the conversion above is not part of the sweep
-    qk_sweep_fused_kernel<QKF_NW, QKF_SLOTS><<<dim3(grid), dim3(64 * QKF_NW), lds_fused, c->stream>>>(a);
+    if (fused_two) qk_sweep_fused_kernel<4, QKF_SLOTS, QKF_XCAP_TWO><<<dim3(grid), dim3(256), lds_fused, c->stream>>>(a);
+    else qk_sweep_fused_kernel<8, QKF_SLOTS, QKF_XCAP_ONE><<<dim3(grid), dim3(512), lds_fused, c->stream>>>(a);
   } else if (f32) {  // complex64 sweep: the ring kernel on fp32 planes; QK_VARIANT does not apply
     qk_sweep_ring_kernel<float><<<dim3(grid), dim3(512), lds_ring, c->stream>>>(a);
   } else if (c->variant == 20) {  // the shipped kernel: LDS-DMA staging ring (K-tile 8, three slots) + 3M complex product
