@@ -13,8 +13,9 @@ MPS construction (the reference's `simulate` loop, the step before the path) hap
 the timed region and is reported separately, like the reference's `r0_circ_sim`.
 
 Rank 0 prints ONE JSON line (contract in the task statement), with `roofline` (dominant
-kernel = qk_sweep_kernel, fp64 MFMA bound) and, at N=1, `cpu_baseline` (the oracle's plain-C
-restatement of the ITensors `inner` loop timed on this host's cores over a bounded sample).
+kernel = the sweep kernel the engine selected, named in the line; fp64 MFMA bound) and, at N=1,
+`cpu_baseline` (the oracle's C restatement of the ITensors `inner` loop on BLAS zgemm, timed on this
+host's cores over a bounded sample; the hand-written loop is timed beside it).
 """
 from __future__ import annotations
 
@@ -96,26 +97,17 @@ def build_or_load_states(name, n, reps, d, gamma, npts, seed, rank, world, worke
     return states, {"built_here": built, "build_wall_s": build_wall, "cpu_s_per_state": float(np.mean(secs))}
 
 
-def sweep_kernel_name(max_padded_bond, precision):
-    """The kernel qk_gram_values selects for a set (include/qkgram.h): by the largest padded bond and the precision."""
-    t = "double" if precision == "f64" else "float"
-    if max_padded_bond <= 16 and precision == "f64" and os.environ.get("QK_WAVE", "1") != "0":
-        return "qk_sweep_wave_kernel<0>"
-    if max_padded_bond <= 32 and os.environ.get("QK_SMALL", "1") != "0":
-        return f"qk_sweep_small_kernel<{t}>"
-    return f"qk_sweep_ring_kernel<{t}>"
-
-
 def cpu_baseline(states, pairs, total_unique, npts, seconds, gpu_vals, threads):
-    """Time the oracle's C restatement on a bounded random sample of this Gram's pairs."""
+    """Time the oracle's C restatement on a bounded random sample of this Gram's pairs: the zgemm-based leg
+    (oracle/overlap_blas.c on scipy's OpenBLAS -- what ITensors' `inner`, KernelPkg.jl:106, runs on) is the
+    reported baseline; the hand-written loop (oracle/overlap_ref.c) is timed on the same pairs beside it."""
     from oracle import c_oracle
-    from qml_cutensornet_amd import engine
 
     rng = np.random.default_rng(0)
     order = rng.permutation(pairs.shape[0])
     dims = np.stack([m.bond_dims() for m in states])
-    # choose the sample size from the algorithmic flops, assuming ~20 GFlop/s per core
-    est_rate = 20e9 * threads
+    # choose the sample size from the algorithmic flops, assuming ~40 GFlop/s per core for the two legs together
+    est_rate = 40e9 * threads
     chosen, acc = [], 0.0
     for t in order:
         i, j = pairs[t]
@@ -127,20 +119,30 @@ def cpu_baseline(states, pairs, total_unique, npts, seconds, gpu_vals, threads):
             break
     chosen = np.asarray(chosen)
     ts = [m.tensors for m in states]
-    t0 = time.perf_counter()
-    vals, _, used = c_oracle.gram_pairs(ts, None, pairs[chosen], threads=threads)
-    dt = time.perf_counter() - t0
-    err = float(np.abs(vals - gpu_vals[chosen]).max())
-    per_pair = dt / len(chosen)
+    legs = {}
+    for name, fn in (("blas", c_oracle.gram_pairs_blas), ("hand_loop", c_oracle.gram_pairs)):
+        t0 = time.perf_counter()
+        vals, _, used = fn(ts, None, pairs[chosen], threads=threads)
+        dt = time.perf_counter() - t0
+        legs[name] = {
+            "value": npts * npts / (dt / len(chosen) * total_unique),
+            "seconds": dt,
+            "gflops": acc / dt / 1e9,
+            "cores": int(used),
+            "parity_max_abs_err_vs_gpu": float(np.abs(vals - gpu_vals[chosen]).max()),
+        }
+    b = legs["blas"]
     return {
-        "value": npts * npts / (per_pair * total_unique),
+        "value": b["value"],
         "unit": "entries/s",
-        "cores": int(used),
+        "cores": b["cores"],
         "kind": "port",
-        "sample": f"{len(chosen)} random pairs of the same Gram ({dt:.1f} s of CPU time on {used} threads, {acc / dt / 1e9:.1f} GFlop/s); "
-        f"rate extrapolated to all {total_unique} unique pairs; oracle/overlap_ref.c (plain-C restatement of KernelPkg.jl:101-109)",
-        "gflops": acc / dt / 1e9,
-        "parity_max_abs_err_vs_gpu": err,
+        "sample": f"{len(chosen)} random pairs of the same Gram ({b['seconds']:.1f} s on {b['cores']} threads, {b['gflops']:.1f} GFlop/s); "
+        f"rate extrapolated to all {total_unique} unique pairs; oracle/overlap_blas.c: C restatement of KernelPkg.jl:101-109 with every "
+        "contraction on zgemm (scipy's OpenBLAS, one pair per thread)",
+        "gflops": b["gflops"],
+        "parity_max_abs_err_vs_gpu": b["parity_max_abs_err_vs_gpu"],
+        "hand_loop": {k: legs["hand_loop"][k] for k in ("value", "gflops", "cores", "parity_max_abs_err_vs_gpu")},
     }
 
 
@@ -236,8 +238,11 @@ def main():
         torch.cuda.current_stream().synchronize()
         return ctx.stats()["kernel_ms"]
 
+    kernel_name = None
+
     for _ in range(args.warmup):
         step()
+    kernel_name = ctx.stats()["kernel_name"] if args.warmup else None
     barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -253,11 +258,18 @@ def main():
     elapsed = float(el.item())
     ms_per_step = 1e3 * elapsed / max(1, args.steps)
     kms = float(np.mean(kernel_ms)) if kernel_ms else float("nan")
+    kernel_name = kernel_name or ctx.stats()["kernel_name"]
 
     # sanity on the result itself (invariants of a Gram of normalised states)
     Kh = host_K.numpy()
     diag_err = float(np.abs(np.diag(Kh) - 1).max())
     sym_err = float(np.abs(Kh - Kh.T).max())
+    # after the timed region: every rank's kernel time and a digest of its copy of K (all ranks hold the full matrix)
+    per_rank = [(kms, hashlib.sha1(np.ascontiguousarray(Kh).tobytes()).hexdigest(), my["padded_flops"] / 1e12)]
+    if world > 1:
+        gathered = [None] * world
+        dist.all_gather_object(gathered, per_rank[0])
+        per_rank = gathered
 
     out = None
     if rank == 0:
@@ -266,10 +278,11 @@ def main():
         # HBM/fabric bytes per launch of the dominant kernel: PMC numbers cannot be collected from inside this
         # process, so the committed rocprofv3 --pmc summary of the SAME workload (profiles/run_rocprof.sh) is quoted.
         traffic = None
-        pmc_file = os.path.join(ROOT, "profiles", "r01", "pmc_summary.json")
+        pmc_file = os.path.join(ROOT, "profiles", "r02", "pmc_summary.json")
         if world == 1 and args.precision == "f64" and args.config == "cfg4" and args.gamma == 1.0 and not args.points and args.seed == 5 and os.path.exists(pmc_file):
             try:
-                traffic = json.load(open(pmc_file))["derived"]["traffic_bytes_per_launch"]
+                pmc = json.load(open(pmc_file))
+                traffic = pmc["derived"]["traffic_bytes_per_launch"] if kernel_name in pmc["kernel"] else None
             except (KeyError, ValueError):
                 traffic = None
         out = {
@@ -289,30 +302,33 @@ def main():
                 "workload": f"{args.config}: {n} qubits x {reps} layers, d={d}, gamma={args.gamma}, truncation 1e-16, {npts}x{npts} symmetric training Gram",
                 "unique_pairs": int(job.plan.total_pairs),
                 "overlaps_per_s": job.plan.total_pairs / (ms_per_step * 1e-3),
-                "parallelism": f"pairs dealt round-robin to {world} rank(s); one {'RCCL' if backend == 'nccl' else backend} all-gather of packed values",
+                "parallelism": f"pairs in cost order dealt in serpentine order to {world} rank(s); one {'RCCL' if backend == 'nccl' else backend} all-gather of packed values",
                 "max_bond_mean": float(chi_max.mean()),
                 "max_bond_max": int(chi_max.max()),
                 "mps_gib": info["device_bytes"] / 2**30,
                 "mps_build_cpu_s_per_state": binfo["cpu_s_per_state"],
                 "diag_err": diag_err,
                 "sym_err": sym_err,
+                "rank_kernel_ms": [round(float(t), 3) for t, _, _ in per_rank],
+                "rank_padded_tflop": [round(float(f), 5) for _, _, f in per_rank],
+                "k_identical_on_all_ranks": len({h for _, h, _ in per_rank}) == 1,
                 **({"f32_vs_f64_max_abs": float(np.abs(Kh - k64_ref).max()), "f32_vs_f64_median_abs": float(np.median(np.abs(Kh - k64_ref)))} if k64_ref is not None else {}),
             },
             "roofline": {
                 "bound": "mfma",  # fp64 matrix cores for f64, fp32 matrix cores for f32
-                "kernel": sweep_kernel_name(info["max_padded_bond"], args.precision),
+                "kernel": kernel_name,
                 "achieved": achieved,
                 "peak": peak,
                 "unit": "TFLOP/s",
                 "frac": achieved / peak,
                 "traffic": traffic,
-                "traffic_source": "profiles/r01/pmc_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, FETCH_SIZE x2 gfx950 correction), bytes per launch" if traffic else None,
+                "traffic_source": "profiles/r02/pmc_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this kernel on this workload, FETCH_SIZE x2 gfx950 correction), bytes per launch" if traffic else None,
                 # L2<->fabric rate those bytes imply at this run's kernel time (Infinity-Cache hits included; HBM peak ~8 TB/s)
                 "traffic_tb_per_s": (traffic / (kms * 1e-3) / 1e12) if (traffic and kms > 0) else None,
                 "kernel_ms": kms,
                 "algorithmic_tflop_per_launch": my["flops"] / 1e12,
                 # the same count with every bond rounded up to the 16-wide MFMA tile (four-product form); the shipped kernel
-                # issues 3/4 of the K-trimmed part of it (3M complex product): see profiles/r01/pmc_summary.json
+                # issues 3/4 of the K-trimmed part of it (3M complex product): see profiles/r02/pmc_summary.json
                 "padded_4m_tflop_per_launch": my["padded_flops"] / 1e12,
                 "algorithmic_gbytes_per_launch": my["bytes"] / 1e9 * (1.0 if args.precision == "f64" else 0.5),
             },
@@ -321,7 +337,7 @@ def main():
             pairs = job.plan.pairs()
             gpu_vals = job.my_vals.cpu().numpy()[: pairs.shape[0]]
             threads = default_workers()
-            log(rank, f"CPU baseline: oracle C restatement on {threads} threads, ~{args.cpu_seconds:.0f}s sample ...")
+            log(rank, f"CPU baseline: oracle C restatement (zgemm leg + hand loop) on {threads} threads, ~{args.cpu_seconds:.0f}s sample each ...")
             out["cpu_baseline"] = cpu_baseline(states, pairs, job.plan.total_pairs, npts, args.cpu_seconds, gpu_vals, threads)
         print(json.dumps(out), flush=True)
     barrier()

@@ -41,7 +41,8 @@ extern "C" {
 /* flags of qk_plan_create() */
 #define QK_PLAN_SYMMETRIC 1u /* Y is X: compute i <= j only, mirror on scatter (G:390-395) */
 #define QK_PLAN_QUADS 2u     /* pairs in 2x2 blocks {i1,i2} x {j1,j2} of consecutive states: one workgroup sweeps a block in
-                                lockstep (experimental: measured no faster than pairs on cfg4).  The pair list then holds 4 entries per
+                                lockstep (experimental: measured no faster than pairs on cfg4; such plans can be CREATED here but are
+                                swept only by the lab library libqklab.so -- qk_gram_values of libqkgram.so returns QK_EINVAL).  The pair list then holds 4 entries per
                                 block (a symmetric plan's diagonal blocks include one mirrored pair i > j, an odd set's last
                                 block repeats its state): scatter handles both. */
 
@@ -63,7 +64,20 @@ typedef struct qk_stats {
   double kernel_ms;    /* device time of the last sweep launch                        */
   int32_t grid;        /* workgroups launched                                         */
   int32_t max_bond;    /* largest padded bond among the two sets                      */
+  int32_t kernel;      /* which sweep kernel ran: QK_KERNEL_* (see qk_kernel_name)    */
+  int32_t precision;   /* 64 or 32: bits of a real of the sets it ran on              */
 } qk_stats;
+
+/* sweep kernels of qk_gram_values (qk_stats.kernel) */
+#define QK_KERNEL_NONE 0
+#define QK_KERNEL_WAVE 1    /* qk_sweep_wave_kernel: one pair per wavefront, bonds <= 16, fp64           */
+#define QK_KERNEL_SMALL 2   /* qk_sweep_small_kernel: X, T in LDS, bonds <= 32                            */
+#define QK_KERNEL_FUSED1 3  /* qk_sweep_fused_kernel<8, 4, 8192>: site-fused sweep, one workgroup per CU  */
+#define QK_KERNEL_FUSED2 4  /* qk_sweep_fused_kernel<4, 4, 4608>: site-fused sweep, two workgroups per CU */
+#define QK_KERNEL_RING 5    /* qk_sweep_ring_kernel: X, T in an L2-resident scratch                       */
+#define QK_KERNEL_LAB 6     /* an experimental kernel (libqklab.so only)                                  */
+/* the kernel's name as rocprofv3 prints it (without the "void " and the argument list) */
+const char* qk_kernel_name(int32_t kernel, int32_t precision);
 
 const char* qk_last_error(void);
 
@@ -95,6 +109,25 @@ int qk_mps_set_create(qk_ctx* ctx, int32_t n_states, int32_t n_sites, const int3
 int qk_mps_set_destroy(qk_mps_set* set);
 int qk_mps_set_info(const qk_mps_set* set, int32_t* n_states, int32_t* n_sites, int32_t* max_padded_bond,
                     int64_t* device_bytes);
+
+/* ---- packed set images: the exchange format between ranks --------------------------------------------------
+ * Replaces the pickled per-MPS sendrecv / send / recv of the reference's ring (G:341-352, 415-419): a rank packs
+ * only ITS share of the states (qk_mps_set_create from host tensors, or qk_mps_set_from_built on the device), the
+ * images are exchanged as flat buffers (one RCCL all-gather of the planes, the small tables beside it) and every rank
+ * assembles the whole set with qk_mps_set_from_packed -- nothing is re-packed element by element, and with RCCL
+ * nothing crosses PCIe.
+ * qk_mps_set_image: the fp64 image of a set: *n_doubles doubles at *planes_dev (valid while the set lives); tables
+ *   copied to dims_true[n_states][n_sites+1] and offsets[n_states][n_sites] (re-plane offsets in doubles); each may be NULL.
+ * qk_mps_set_from_packed: a set of n_states states whose site tensors lie in the device buffer `planes_dev`
+ *   (n_doubles doubles, copied device-to-device into memory the new set owns) at the given offsets, each in the
+ *   padded split-plane layout of qk_mps_set_create (what qk_mps_set_image hands out).
+ * qk_mps_set_copy_image: the planes copied into `dst` (n_doubles doubles; a device buffer -- for example the send
+ *   buffer of the all-gather -- or a host buffer: the direction is inferred from the pointer).
+ * In qk_mps_set_from_packed `planes` may likewise be a device or a host buffer.                                     */
+int qk_mps_set_image(const qk_mps_set* set, int64_t* n_doubles, const double** planes_dev, int32_t* dims_true, int64_t* offsets);
+int qk_mps_set_copy_image(const qk_mps_set* set, double* dst, int64_t n_doubles);
+int qk_mps_set_from_packed(qk_ctx* ctx, int32_t n_states, int32_t n_sites, const int32_t* dims_true, const int64_t* offsets,
+                           const double* planes_dev, int64_t n_doubles, qk_mps_set** out);
 
 /* Precision of a set's device image: 64 (complex128 planes, what qk_mps_set_create builds) or 32.
  * qk_mps_set_to_f32 makes a complex64 copy on the device (same layout, same element offsets).  A sweep whose two
@@ -134,10 +167,12 @@ int qk_plan_stats(const qk_plan* plan, qk_stats* out); /* algorithmic flops/byte
  *     z_dev[2p], z_dev[2p+1] = re, im of z_p  (optional, may be NULL)
  * One persistent launch; returns after enqueueing (asynchronous).
  * yset = NULL means Y is X.
- * The sweep kernel is chosen from the two sets' largest padded bond: 16 -> one pair per wavefront, entirely in
- * registers (fp64); <= 32 -> X and T resident in LDS, site tensors streamed; otherwise the general ring kernel
- * (X / T in an L2-resident scratch).  All three compute the same chain of complex GEMMs on the matrix cores and
- * agree to rounding (tests/test_gpu_parity.py); QK_WAVE=0 / QK_SMALL=0 in the environment force the general one.  */
+ * The sweep kernel is chosen from the two sets' largest padded bond and precision: 16 (fp64) -> one pair per
+ * wavefront, entirely in registers; <= 32 -> X and T resident in LDS, site tensors streamed; larger fp64 bonds -> the
+ * site-fused sweep (X in LDS, T in registers, qk_fused.h); complex64 sets and bonds > 512 -> the ring sweep (X / T in
+ * an L2-resident scratch).  All compute the same chain of complex GEMMs on the matrix cores and agree to rounding
+ * (tests/test_gpu_parity.py); QK_WAVE=0 / QK_SMALL=0 / QK_FUSED=0 in the environment fall back to the next more
+ * general one, QK_FUSED=2 uses the fused sweep from bond 17, QK_FUSED_WGS=1|2 fixes its workgroups per CU.          */
 int qk_gram_values(qk_ctx* ctx, const qk_mps_set* xset, const qk_mps_set* yset, const qk_plan* plan,
                    double* values_dev, double* z_dev);
 
@@ -162,14 +197,6 @@ int qk_gram_host(qk_ctx* ctx, const qk_mps_set* xset, const qk_mps_set* yset, do
 int qk_overlaps_host(qk_ctx* ctx, const qk_mps_set* xset, const qk_mps_set* yset, double* out);
 
 int qk_get_stats(qk_ctx* ctx, qk_stats* out);
-
-/* Diagnostic build only (QK_VARIANT=9): cycle sums of the instrumented sweep kernel's sections:
- * out8 = {fetch issue, MFMA block, epilogue stores, stash (+vmcnt wait), barrier, phase prologue,
- *         phase-end barrier, wave lifetime}.  Never used by the timed kernels. */
-int qk_debug_profile(qk_ctx* ctx, unsigned long long* out8);
-/* Diagnostic: TFLOP/s of the MFMA block with the sweep's per-step ingredients added back one at a
- * time.  which = 8*(8-wave workgroup) + {0 bare, 1 +barrier, 2 +stash, 3 +global fetch, 4 +deep fetch}. */
-int qk_debug_mma_bench(qk_ctx* ctx, int which, int wgs_per_cu, int reps, double* tflops);
 
 /* Device self-test of the f64 MFMA fragment maps the kernels rely on (returns
  * 0 if the 16x16x4 product of two known matrices matches the host result). */

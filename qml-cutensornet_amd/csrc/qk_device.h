@@ -36,8 +36,4 @@ struct SweepArgs {
 
 // Workgroup barrier that publishes LDS writes only: it does NOT drain outstanding global loads or LDS-DMAs
 // (a __syncthreads() would wait vmcnt(0) and cancel the prefetch that is meant to stay in flight).
-#ifdef QKF_EXP_NOBAR  // timing experiment of the fused sweep: no workgroup barriers (results are wrong)
-__device__ __forceinline__ void qk_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
-#else
 __device__ __forceinline__ void qk_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
-#endif

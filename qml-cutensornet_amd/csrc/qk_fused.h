@@ -1,28 +1,34 @@
-// qk_fused.h -- the site-fused sweep (qk_sweep_fused_kernel): the shipped fp64 hot path for sets with bonds > 16.
+// qk_fused.h -- the site-fused sweep (qk_sweep_fused_kernel): the shipped fp64 hot path for sets with a bond > 32.
 //
 // One overlap <x|y> (reference: MPS.vdot, gpu_backend/kernel_state_ansatz.py:380; KernelPkg.jl:106) is the chain
 //     X_0 = 1,   T[a, p, b'] = sum_b X[b, a] B_k[b, p, b'],   X'[b', a'] = sum_{a, p} T[a, p, b'] conj(A_k[a, p, a'])
 // The ring sweep (qk_ring.h) runs it as two GEMMs per site with X and T in an L2-resident scratch: 40 % of its fabric
 // traffic is the T round trip and every GEMM starts with a write->read stall.  Here T never exists in memory:
 //
-//   * ONE 8-wave workgroup per CU (256 VGPRs per wave, the whole 160 KiB LDS) carries a pair; X lives in LDS
-//     (complex128 interleaved, [b][a] row-major = "k-major" for the next site) whenever b^ a^ <= XCAP (8192: 98.7 % of
-//     the sites and 88 % of the matrix work of the 60-qubit x 6-layer headline workload);
-//   * the unit of work is an ITEM (ta, tb) = one 16-row block of a times one 16-column block of b'.  Phase 1: the wave
-//     that owns the item computes the two tiles T[ta, p = 0/1, tb] (K = b) and KEEPS them in registers -- the C/D
-//     layout of v_mfma_f64_16x16x4_f64 (register r of lane (q, j) = C[q + 4r][j]) is the A-operand layout of a k-major
-//     operand with k-step r, so the tiles are fed straight back as the A operand of phase 2:
-//     X'[tb, tn] += sum_p T_p^T conj(A_k[ta rows, p, tn cols]) for every column block tn of a'.  The sum over ta (other
-//     waves' items) is taken in LDS with ds_add_f64;
+//   * X lives in LDS (complex128 interleaved, [b][a] row-major = "k-major" for the next site) whenever it fits the
+//     workgroup's X buffer (98.7 % of the sites and 88 % of the matrix work of the 60-qubit x 6-layer headline workload
+//     at 8192 elements).  When X and X' fit side by side, X' is built at the other end of the buffer (zeroed while the
+//     previous site's result is consumed); otherwise it overwrites X after a barrier;
+//   * the unit of work is an ITEM (ta, tb, p): one 16 x 16 tile T[ta, p, tb], dealt round-robin to the waves.
+//     Phase 1: the wave computes its tile (K = b) and KEEPS it in registers -- the C/D layout of v_mfma_f64_16x16x4_f64
+//     (register r of lane (q, j) = C[q + 4r][j]) is the A-operand layout of a k-major operand with k-step r, so the
+//     tile is fed straight back as the A operand of phase 2:
+//         X'[tb rows, tn cols] += T^T conj(A_k[ta rows, p, tn cols])     for every column block tn of a',
+//     added into LDS with ds_add_f64 (the sum over ta and p is taken by the LDS);
 //   * site tensors are read straight from the set image into B-operand fragments: one 16-byte load per lane and k-step
-//     (complex128 interleaved image, rows of 16 elements = 256 contiguous bytes), prefetched one group of four k-steps
-//     ahead.  No staging ring, no per-K-tile barrier: a wave runs its items autonomously and the workgroup meets at
-//     three barriers per site (X read / X' zeroed / X' complete).  The fragments that several items share are
-//     re-read through L1/L2, never through the fabric;
+//     (complex128 interleaved image, rows of 16 elements = 256 contiguous bytes), four k-steps in flight per wave.  The
+//     stream never drains: the last group of a tile loads the first group of the wave's next tile, of its first
+//     phase-2 group, or of its first tile of the NEXT site, across the barriers.  No staging ring, no per-K-tile
+//     barrier: a wave runs its items autonomously and the workgroup meets at two or three barriers per site.  The
+//     fragments that several items share are re-read through L1/L2, never through the fabric;
 //   * K is walked in units of 4 up to the TRUE bond; the complex product is the 3M form of the ring kernel;
-//   * sites too large for LDS run in STRIPS: X is read from a per-workgroup global buffer (A-operand fragments loaded
-//     like the site tensors), X' is accumulated strip by strip (a block of b' rows at a time, sized so that the
-//     strip's items fit the T registers and its rows the LDS) and written back to the other global buffer.
+//   * sites too large for the LDS run in STRIPS: X is read from a per-workgroup global buffer (A-operand fragments
+//     loaded like the site tensors), X' is accumulated a block of b' rows at a time (as many as fit the LDS), items in
+//     rounds of (waves x slots), and written to the other global buffer;
+//   * per-site control is a 48-byte record per site, computed by all threads at pair set-up.
+// Two launch shapes (chosen per launch from the plan, qkgram.hip): one 8-wave workgroup per CU with an 8192-element X
+// buffer, or two 4-wave workgroups with 4608 elements each -- the second workgroup fills the first one's barriers and
+// per-site set-up, which pays while most of the work sits in sites that fit the smaller buffer.
 // fp64 only: the f32 MFMA's C layout (C[4q + r][j]) is not an operand layout (the complex64 sweep stays on qk_ring.h).
 #pragma once
 #include "qk_device.h"
@@ -39,14 +45,10 @@ static constexpr int QKF_SLOTS = 4;  // T slots (items) per wave and round: 16 V
 // one complex k-step, 3M form: (ar + i ai) * (br + i s bi), s = +1 | -1 (CONJB)
 template <bool CONJB>
 __device__ __forceinline__ void qkf_kstep(v4d& p1, v4d& p2, v4d& p3, const double ar, const double ai, const double br, const double bi) {
-#ifdef QKF_EXP_NOMFMA  // timing experiment: everything but the matrix instructions (operands stay live)
-  asm volatile("" ::"v"(ar), "v"(ai), "v"(br), "v"(bi));
-#else
   const double sa = ar + ai, sb = CONJB ? br - bi : br + bi;
   p1 = __builtin_amdgcn_mfma_f64_16x16x4f64(ar, br, p1, 0, 0, 0);
   p2 = __builtin_amdgcn_mfma_f64_16x16x4f64(ai, bi, p2, 0, 0, 0);
   p3 = __builtin_amdgcn_mfma_f64_16x16x4f64(sa, sb, p3, 0, 0, 0);
-#endif
 }
 
 struct QkfTile {  // a 16 x 16 complex tile in the C/D register layout: 16 VGPRs
@@ -56,11 +58,7 @@ struct QkfTile {  // a 16 x 16 complex tile in the C/D register layout: 16 VGPRs
 // 16-byte fragment load from a wave-uniform base and a 32-bit lane offset (in elements): the addressing form
 // global_load_dwordx4 v, v_off, s[base:base+1] -- one VGPR of address state per stream
 __device__ __forceinline__ v2d qkf_ldg(const v2d* __restrict__ base, const unsigned off) {
-#ifdef QKF_EXP_NOLOAD  // timing experiment: no fragment loads from global memory
-  return (v2d){(double)off, 1.0};
-#else
   return *reinterpret_cast<const v2d*>(reinterpret_cast<const char*>(base) + (size_t)(off * 16u));
-#endif
 }
 __device__ __forceinline__ v2d qkf_ldx(const v2d* __restrict__ base, const unsigned off) { return qkf_ldg(base, off); }
 __device__ __forceinline__ v2d qkf_ldx(const lds_v2d* base, const unsigned off) { return base[off]; }
@@ -136,32 +134,33 @@ __device__ __forceinline__ void qkf_p2_item(const QkfTile& t, v2d (&fr)[4], cons
       __builtin_amdgcn_sched_barrier(0);
     }
     const v4d re = p1 + p2, im = p3 - p1 + p2;
-#ifndef QKF_EXP_NOADD
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       __hip_atomic_fetch_add(d + (long)r * 8 * a2, re[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       __hip_atomic_fetch_add(d + (long)r * 8 * a2 + 1, im[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
-#else
-    if (re[0] + im[1] + re[2] + im[3] == 1.2345e300) d[0] = 1.0;
-#endif
     d += 2 * TILE;
   }
 }
 
 // The T tiles of a wave live in registers, S slots.  The slot loops are NOT unrolled (unrolled, every slot drags ~50
-// VGPRs of hoisted address state through the whole sweep) and the working slot is always T[S-1]: when a phase has more
-// items than waves the array is rotated by one slot before each item (phase 1 makes all S turns, so that item s ends
-// in slot s; phase 2 turns once per item, which brings item s to slot S-1).
+// VGPRs of hoisted address state through the whole sweep) and the working slot is always T[S-1]: when a round gives
+// the waves up to L > 1 items each, the last L slots are turned by one before each item (phase 1 makes all L turns, so
+// that item s ends in slot S-L+s; phase 2 turns once per item, which brings item s to slot S-1).  S = 4 is assumed.
 template <int S>
-__device__ __forceinline__ void qkf_rotate(QkfTile (&T)[S]) {
-#ifdef QKF_EXP_NOROT
-  return;
-#endif
-  const QkfTile t0 = T[0];
+__device__ __forceinline__ void qkf_rotate(QkfTile (&T)[S], const int L) {  // turn the last L slots by one: T[S-L] goes to T[S-1]
+  if (L == 2) {
+    const QkfTile t = T[S - 2];
+    T[S - 2] = T[S - 1], T[S - 1] = t;
+  } else if (L == 3) {
+    const QkfTile t = T[S - 3];
+    T[S - 3] = T[S - 2], T[S - 2] = T[S - 1], T[S - 1] = t;
+  } else if (L >= 4) {
+    const QkfTile t0 = T[0];
 #pragma unroll
-  for (int e = 0; e + 1 < S; ++e) T[e] = T[e + 1];
-  T[S - 1] = t0;
+    for (int e = 0; e + 1 < S; ++e) T[e] = T[e + 1];
+    T[S - 1] = t0;
+  }
 }
 
 // What a site needs: bonds, tile counts, where its X / X' live and how its items are cut into strips.
@@ -283,10 +282,8 @@ __global__ __launch_bounds__(64 * NW, 2) void qk_sweep_fused_kernel(const SweepA
       const int n_out = sc.b2 * a2;
       const bool pingpong = small && a * b + n_out <= XCAP;
       const int ob = !small ? 0 : pingpong ? (xb == 0 ? XCAP - n_out : 0) : 0;  // where X' (or the strip of X') is built
-#ifndef QKF_EXP_NOZERO
       if (pingpong)
         for (int e = tid; e < n_out; e += NT) XL[ob + e] = (v2d){0.0, 0.0};
-#endif
       QKF_STAMP(1);  // X moved between LDS and the global buffer
       for (int s0 = 0; s0 < nt; s0 += W) {
         const int w = min(W, nt - s0), items = 2 * mt * w;
@@ -296,17 +293,18 @@ __global__ __launch_bounds__(64 * NW, 2) void qk_sweep_fused_kernel(const SweepA
         }
         QKF_STAMP(6);  // strip zeroing
         for (int r0 = 0; r0 < items; r0 += NW * S) {  // (one round on the LDS-resident path)
-          const bool multi = items - r0 > NW;  // more than one slot in use
+          const int L = min(S, (items - r0 + NW - 1) / NW);  // slots in use this round (the same for every wave)
+          const bool multi = L > 1;
           const int it0 = r0 + wave;          // this wave's items: it0, it0 + NW, ...
           // ---- phase 1: the T tile of each of this wave's items
           auto phase1 = [&](auto xbase) __attribute__((always_inline)) {
 #pragma unroll 1
-            for (int s = 0; s < (multi ? S : 1); ++s) {
-              if (multi) qkf_rotate<S>(T);
+            for (int s = 0; s < L; ++s) {
+              if (multi) qkf_rotate<S>(T, L);
               const int it = it0 + NW * s;
               if (it < items) {
                 const int u = it >> 1, tbl = (u * sc.inv) >> 20, ta = u - tbl * mt;
-                const bool more = s + 1 < S && it + NW < items;  // another tile follows in this phase; else phase 2 starts with item it0
+                const bool more = s + 1 < L && it + NW < items;  // another tile follows in this phase; else phase 2 starts with item it0
                 const QkfStream nxt = more ? b_stream(sc, s0, it + NW) : a_stream(sc, it0);
                 qkf_p1_tile(T[S - 1], fr, primed, b_stream(sc, s0, it), xbase, (unsigned)(q * a + ta * TILE + j), 4 * a, sc.nks, nxt);
                 primed = true;
@@ -330,7 +328,7 @@ __global__ __launch_bounds__(64 * NW, 2) void qk_sweep_fused_kernel(const SweepA
           for (int s = 0; s < S; ++s) {
             const int it = it0 + NW * s;
             if (it >= items) break;
-            if (multi) qkf_rotate<S>(T);
+            if (multi) qkf_rotate<S>(T, L);
             const int u = it >> 1, tbl = (u * sc.inv) >> 20, ta = u - tbl * mt;
             const int kmax = min(4, (sc.at - ta * TILE + 3) >> 2);
             const bool more = s + 1 < S && it + NW < items;

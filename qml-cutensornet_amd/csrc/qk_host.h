@@ -1,6 +1,7 @@
-// qk_host.h -- host-side state shared by the two translation units of libqkgram.so:
-//   qkgram.hip  the C ABI, the planner and the shipped kernels;
-//   qk_lab.hip  the experimental / diagnostic kernels kept for A/B measurements (QK_VARIANT != 20).
+// qk_host.h -- host-side state shared by the translation units:
+//   qkgram.hip    the C ABI, the planner and the shipped sweep kernels      } libqkgram.so
+//   qk_build.hip  the device MPS builder                                    }
+//   qk_lab.hip    experimental / diagnostic kernels for A/B measurements: only in libqklab.so (-DQK_LAB, tools/)
 #pragma once
 #include "../../include/qkgram.h"
 
@@ -30,8 +31,8 @@ struct qk_ctx {
   size_t scratch_bytes = 0;
   unsigned long long* counter = nullptr;
   unsigned long long* prof = nullptr;  // 8 cycle sums of the diagnostic variant
-  int variant = 20;    // sweep kernel variant (QK_VARIANT): 20 = shipped (ring sweep: LDS-DMA ring + 3M product); 17 = lean register-staged sweep;
-                       // 0, 2, 12, 13, 14, 16, 21, 23 = other kernels kept for A/B; 9, 19 = instrumented
+  int variant = 20;    // 20 = the shipped kernels.  Anything else exists only in libqklab.so (QK_VARIANT there: 17 = lean register-staged
+                       // sweep; 0, 2, 12, 13, 14, 16, 21, 23 = other kernels kept for A/B; 9, 19 = instrumented)
   int wgs_per_cu = 2;  // resident workgroups per CU (QK_WGS_PER_CU)
   bool wave_path = true;   // fp64 sets whose bonds are all <= 16 use the one-wave-per-pair register sweep (QK_WAVE=0 opts out)
   bool small_path = true;  // sets whose bonds are all <= 32 use the LDS-resident small-bond sweep (QK_SMALL=0 opts out)

@@ -1,7 +1,9 @@
 // qk_lab.hip -- experimental and diagnostic kernels of the Gram engine, kept selectable (QK_VARIANT) because
-// DESIGN.md's investigation quotes measurements of each of them.  Nothing here is on the shipped path: the product
-// kernels live in qk_ring.h / qkgram.hip.  Same library, same C ABI (the two debug entry points are defined here).
+// DESIGN.md's investigation quotes measurements of each of them.  Nothing here is on the shipped path and nothing here
+// is in libqkgram.so: this file is linked only into libqklab.so (built with -DQK_LAB, loaded by tools/), which exports
+// the same C ABI plus the entry points of qk_lab.h.
 #include "qk_host.h"
+#include "qk_lab.h"
 #include "qk_ring.h"
 
 #include <algorithm>

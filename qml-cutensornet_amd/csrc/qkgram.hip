@@ -10,8 +10,10 @@
 // (v_mfma_f64_16x16x4_f64), and finally writes |<x|y>|^2.
 //
 //
-// Files: this one = C ABI (include/qkgram.h), packing, planner, small kernels, launches;  qk_ring.h = the sweep
-// kernels (the hot path);  qk_lab.hip = experimental / diagnostic kernels selectable with QK_VARIANT.
+// Files: this one = C ABI (include/qkgram.h), packing, planner, small kernels, launches;  qk_fused.h = the site-fused
+// sweep (the fp64 hot path);  qk_ring.h = the ring sweep (complex64, very large bonds), the small-bond and the
+// one-wave sweeps;  qk_build.hip = the device MPS builder.  qk_lab.hip (experimental / diagnostic kernels) is NOT part of
+// libqkgram.so: it is linked only into libqklab.so (-DQK_LAB), which tools/ load for A/B measurements.
 // Written for gfx950 only: 64-lane wavefronts, 160 KiB LDS per CU, no portability layer.
 #include "qk_host.h"
 #include "qk_ring.h"
@@ -47,6 +49,17 @@ int qk_fail(int code, const char* fmt, ...) {
 extern "C" const char* qk_last_error(void) { return g_err.c_str(); }
 
 static inline int pad16(int x) { return (x + TILE - 1) / TILE * TILE; }
+
+// a device allocation that is released on every exit path (HIP_TRY returns early)
+struct DevBuf {
+  void* p = nullptr;
+  ~DevBuf() {
+    if (p) (void)hipFree(p);
+  }
+  hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes); }
+  template <typename T>
+  T* as() const { return static_cast<T*>(p); }
+};
 
 // ----------------------------------------------------------------------------------------
 // host: packing one MPS into the padded planar device image
@@ -331,6 +344,8 @@ extern "C" int qk_device_count(void) {
   return n;
 }
 
+static int ctx_init(qk_ctx* c, int device_id, int num_cus);
+
 extern "C" int qk_ctx_create(int device_id, qk_ctx** out) {
   if (!out) return fail(QK_EINVAL, "qk_ctx_create: null out");
   int n = 0;
@@ -346,8 +361,18 @@ extern "C" int qk_ctx_create(int device_id, qk_ctx** out) {
     return fail(QK_EDEVICE, "qk_ctx_create: device %d is %s; this library is built for gfx950 only", device_id, prop.gcnArchName);
   qk_ctx* c = new (std::nothrow) qk_ctx;
   if (!c) return fail(QK_ENOMEM, "qk_ctx_create: out of memory");
+  const int rc_init = ctx_init(c, device_id, prop.multiProcessorCount);
+  if (rc_init != QK_OK) {
+    qk_ctx_destroy(c);  // releases whatever was created before the failure
+    return rc_init;
+  }
+  *out = c;
+  return QK_OK;
+}
+
+static int ctx_init(qk_ctx* c, int device_id, int num_cus) {
   c->device = device_id;
-  c->num_cus = prop.multiProcessorCount;
+  c->num_cus = num_cus;
   HIP_TRY(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
   c->stream = c->own_stream;
   HIP_TRY(hipEventCreate(&c->ev0));
@@ -361,26 +386,28 @@ extern "C" int qk_ctx_create(int device_id, qk_ctx** out) {
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(qk_sweep_small_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(qk_sweep_fused_kernel<8, QKF_SLOTS, QKF_XCAP_ONE>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(qk_sweep_fused_kernel<4, QKF_SLOTS, QKF_XCAP_TWO>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
+#ifdef QK_LAB  // libqklab.so only: the experimental kernels of qk_lab.hip, selectable with QK_VARIANT
   {
     const int rc = qk_lab_init(c);
     if (rc != QK_OK) return rc;
   }
   if (const char* v = std::getenv("QK_VARIANT")) c->variant = std::atoi(v);
+#endif
   if (const char* v = std::getenv("QK_SMALL")) c->small_path = std::atoi(v) != 0;
   if (const char* v = std::getenv("QK_WAVE")) c->wave_path = std::atoi(v) != 0;
   if (const char* v = std::getenv("QK_FUSED")) c->fused_path = std::atoi(v);
   if (const char* v = std::getenv("QK_FUSED_WGS")) c->fused_wgs = std::max(0, std::min(2, std::atoi(v)));
   if (const char* v = std::getenv("QK_WGS_PER_CU")) c->wgs_per_cu = std::max(1, std::min(4, std::atoi(v)));
-  *out = c;
   return QK_OK;
 }
 
 extern "C" int qk_ctx_destroy(qk_ctx* c) {
   if (!c) return QK_OK;
   (void)hipSetDevice(c->device);
-  (void)hipStreamSynchronize(c->stream);
+  if (c->stream) (void)hipStreamSynchronize(c->stream);
   if (c->scratch) (void)hipFree(c->scratch);
   if (c->counter) (void)hipFree(c->counter);
+  if (c->prof) (void)hipFree(c->prof);
   if (c->ev0) (void)hipEventDestroy(c->ev0);
   if (c->ev1) (void)hipEventDestroy(c->ev1);
   if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
@@ -457,12 +484,16 @@ extern "C" int qk_mps_set_create(qk_ctx* c, int32_t n_states, int32_t n_sites, c
       return fail(QK_EDEVICE, "qk_mps_set_create: upload failed: %s", hipGetErrorString(e));
     }
   }
-  HIP_TRY(hipMalloc(&m->d_dims, pad.size() * sizeof(int32_t)));
-  HIP_TRY(hipMalloc(&m->d_offs, offs.size() * sizeof(int64_t)));
-  HIP_TRY(hipMemcpy(m->d_dims, pad.data(), pad.size() * sizeof(int32_t), hipMemcpyHostToDevice));
-  HIP_TRY(hipMalloc(&m->d_true, pad.size() * sizeof(int32_t)));
-  HIP_TRY(hipMemcpy(m->d_true, bond_dims, pad.size() * sizeof(int32_t), hipMemcpyHostToDevice));
-  HIP_TRY(hipMemcpy(m->d_offs, offs.data(), offs.size() * sizeof(int64_t), hipMemcpyHostToDevice));
+  e = hipMalloc(&m->d_dims, pad.size() * sizeof(int32_t));
+  if (e == hipSuccess) e = hipMalloc(&m->d_offs, offs.size() * sizeof(int64_t));
+  if (e == hipSuccess) e = hipMalloc(&m->d_true, pad.size() * sizeof(int32_t));
+  if (e == hipSuccess) e = hipMemcpy(m->d_dims, pad.data(), pad.size() * sizeof(int32_t), hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(m->d_true, bond_dims, pad.size() * sizeof(int32_t), hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(m->d_offs, offs.data(), offs.size() * sizeof(int64_t), hipMemcpyHostToDevice);
+  if (e != hipSuccess) {
+    qk_mps_set_destroy(m);
+    return fail(QK_EDEVICE, "qk_mps_set_create: table upload failed: %s", hipGetErrorString(e));
+  }
   *out = m;
   return QK_OK;
 }
@@ -490,6 +521,73 @@ extern "C" int qk_mps_set_info(const qk_mps_set* m, int32_t* n_states, int32_t* 
 }
 
 extern "C" int qk_mps_set_precision(const qk_mps_set* m) { return m ? m->precision : 0; }
+
+extern "C" int qk_mps_set_image(const qk_mps_set* m, int64_t* n_doubles, const double** planes_dev, int32_t* dims_true, int64_t* offsets) {
+  if (!m) return fail(QK_EINVAL, "qk_mps_set_image: null set");
+  if (m->precision != 64) return fail(QK_EINVAL, "qk_mps_set_image: only fp64 sets are exchanged");
+  if (n_doubles) *n_doubles = m->bytes / (int64_t)sizeof(double);
+  if (planes_dev) *planes_dev = m->d_data;
+  if (dims_true) std::memcpy(dims_true, m->dims_true.data(), m->dims_true.size() * sizeof(int32_t));
+  if (offsets) {
+    HIP_TRY(hipSetDevice(m->ctx->device));
+    HIP_TRY(hipStreamSynchronize(m->ctx->stream));
+    HIP_TRY(hipMemcpy(offsets, m->d_offs, (size_t)m->n_states * m->n_sites * sizeof(int64_t), hipMemcpyDeviceToHost));
+  }
+  return QK_OK;
+}
+
+extern "C" int qk_mps_set_copy_image(const qk_mps_set* m, double* dst, int64_t n_doubles) {
+  if (!m || !dst) return fail(QK_EINVAL, "qk_mps_set_copy_image: null argument");
+  if (m->precision != 64) return fail(QK_EINVAL, "qk_mps_set_copy_image: only fp64 sets are exchanged");
+  if (n_doubles * (int64_t)sizeof(double) < m->bytes) return fail(QK_EINVAL, "qk_mps_set_copy_image: destination holds %lld doubles, the image has %lld", (long long)n_doubles, (long long)(m->bytes / 8));
+  HIP_TRY(hipSetDevice(m->ctx->device));
+  HIP_TRY(hipMemcpyAsync(dst, m->d_data, (size_t)m->bytes, hipMemcpyDefault, m->ctx->stream));
+  HIP_TRY(hipStreamSynchronize(m->ctx->stream));
+  return QK_OK;
+}
+
+extern "C" int qk_mps_set_from_packed(qk_ctx* c, int32_t n_states, int32_t n_sites, const int32_t* dims_true, const int64_t* offsets,
+                                      const double* planes_dev, int64_t n_doubles, qk_mps_set** out) {
+  if (!c || !out || !dims_true || !offsets || !planes_dev) return fail(QK_EINVAL, "qk_mps_set_from_packed: null argument");
+  if (n_states <= 0 || n_sites <= 0 || n_doubles <= 0) return fail(QK_EINVAL, "qk_mps_set_from_packed: empty set");
+  const int stride = n_sites + 1;
+  std::vector<int32_t> pad((size_t)n_states * stride);
+  int max_pad = 0;
+  for (int s = 0; s < n_states; ++s) {
+    const int32_t* d = dims_true + (size_t)s * stride;
+    if (d[0] != 1 || d[n_sites] != 1) return fail(QK_EINVAL, "qk_mps_set_from_packed: state %d: boundary bonds must be 1", s);
+    for (int k = 0; k <= n_sites; ++k) {
+      if (d[k] <= 0) return fail(QK_EINVAL, "qk_mps_set_from_packed: state %d: non-positive bond %d", s, k);
+      pad[(size_t)s * stride + k] = pad16(d[k]);
+      max_pad = std::max(max_pad, pad16(d[k]));
+    }
+    for (int k = 0; k < n_sites; ++k) {  // every tensor must lie inside the buffer, 16-byte aligned
+      const int64_t off = offsets[(size_t)s * n_sites + k], sz = 2ll * pad[(size_t)s * stride + k] * 2 * pad[(size_t)s * stride + k + 1];
+      if (off < 0 || (off & 1) || off + sz > n_doubles) return fail(QK_EINVAL, "qk_mps_set_from_packed: state %d site %d: tensor [%lld, %lld) outside the %lld-double image", s, k, (long long)off, (long long)(off + sz), (long long)n_doubles);
+    }
+  }
+  HIP_TRY(hipSetDevice(c->device));
+  qk_mps_set* m = new (std::nothrow) qk_mps_set;
+  if (!m) return fail(QK_ENOMEM, "qk_mps_set_from_packed: out of memory");
+  m->ctx = c, m->n_states = n_states, m->n_sites = n_sites, m->max_pad = max_pad;
+  m->dims_true.assign(dims_true, dims_true + (size_t)n_states * stride);
+  m->bytes = n_doubles * (int64_t)sizeof(double);
+  hipError_t e = hipMalloc(&m->d_data, (size_t)m->bytes);
+  if (e == hipSuccess) e = hipMalloc(&m->d_dims, pad.size() * sizeof(int32_t));
+  if (e == hipSuccess) e = hipMalloc(&m->d_true, pad.size() * sizeof(int32_t));
+  if (e == hipSuccess) e = hipMalloc(&m->d_offs, (size_t)n_states * n_sites * sizeof(int64_t));
+  if (e == hipSuccess) e = hipMemcpyAsync(m->d_data, planes_dev, (size_t)m->bytes, hipMemcpyDefault, c->stream);  // device or host source
+  if (e == hipSuccess) e = hipMemcpyAsync(m->d_dims, pad.data(), pad.size() * sizeof(int32_t), hipMemcpyHostToDevice, c->stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(m->d_true, dims_true, pad.size() * sizeof(int32_t), hipMemcpyHostToDevice, c->stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(m->d_offs, offsets, (size_t)n_states * n_sites * sizeof(int64_t), hipMemcpyHostToDevice, c->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+  if (e != hipSuccess) {
+    qk_mps_set_destroy(m);
+    return fail(QK_EDEVICE, "qk_mps_set_from_packed: %s", hipGetErrorString(e));
+  }
+  *out = m;
+  return QK_OK;
+}
 
 extern "C" int qk_mps_set_to_f32(qk_ctx* c, const qk_mps_set* src, qk_mps_set** out) {
   if (!c || !src || !out) return fail(QK_EINVAL, "qk_mps_set_to_f32: null argument");
@@ -566,6 +664,8 @@ extern "C" int qk_gram_values(qk_ctx* c, const qk_mps_set* xs, const qk_mps_set*
   c->last.max_bond = std::max(xs->max_pad, ys->max_pad);
   c->last.kernel_ms = 0;
   c->last.grid = 0;
+  c->last.kernel = QK_KERNEL_NONE;
+  c->last.precision = xs->precision;
   if (np == 0) return QK_OK;
   int rc = ensure_plan_uploaded(c, plan);
   if (rc != QK_OK) return rc;
@@ -611,30 +711,38 @@ extern "C" int qk_gram_values(qk_ctx* c, const qk_mps_set* xs, const qk_mps_set*
   a.scratch = c->scratch, a.x_plane = x_plane, a.t_plane = t_plane;
   a.counter = c->counter;
   a.prof = c->prof;
-  a.debug_flags = 0;
+  a.debug_flags = 0, a.prio_mode = 0;
+#ifdef QK_LAB  // timing experiments of the lab kernels (they give wrong results by construction): libqklab.so only
   if (const char* v = std::getenv("QK_DEBUG_FLAGS")) a.debug_flags = std::atoi(v);
-  a.prio_mode = 0;
   if (const char* v = std::getenv("QK_PRIO")) a.prio_mode = std::atoi(v);
+#endif
   HIP_TRY(hipMemsetAsync(c->counter, 0, sizeof(unsigned long long), c->stream));
   HIP_TRY(hipEventRecord(c->ev0, c->stream));
+  int launched_grid = grid;
   // per-pair site metadata in LDS behind the three ring slots: 4 (n+1) ints + 2 n int64 (+ alignment)
   const size_t lds_ring = 3 * 16 * 1024 + 16 + (size_t)(4 * (xs->n_sites + 1) + 2) * sizeof(int) + (size_t)2 * xs->n_sites * sizeof(long long);
   if (lds_ring > 80 * 1024) return fail(QK_EINVAL, "qk_gram_values: %d sites need %zu bytes of LDS per workgroup (limit 80 KiB for 2 workgroups per CU)", xs->n_sites, lds_ring);
   const size_t esz = f32 ? sizeof(float) : sizeof(double);
   const size_t lds_small = (size_t)(3 * 2 * (64 / esz) * 64 + 6 * 32 * 32) * esz + 16 + (size_t)(4 * (xs->n_sites + 1) + 2) * sizeof(int) + (size_t)2 * xs->n_sites * sizeof(long long);
-  if (quad) {  // 2x2 blocks of pairs per workgroup (QK_PLAN_QUADS plans; experimental kernel in qk_lab.hip), either precision
+  if (quad) {  // 2x2 blocks of pairs per workgroup (QK_PLAN_QUADS plans): an experimental kernel of the lab library
+#ifdef QK_LAB
     const int rc_quad = qk_lab_launch_quad(c, a, grid, xs->n_sites, f32);
     if (rc_quad != QK_OK) return rc_quad;
+    c->last.kernel = QK_KERNEL_LAB;
+#else
+    return fail(QK_EINVAL, "qk_gram_values: QK_PLAN_QUADS plans are swept by an experimental kernel that only libqklab.so contains");
+#endif
   } else if (c->variant == 20 && c->wave_path && !f32 && std::max(xs->max_pad, ys->max_pad) <= 16) {
     // every bond <= 16: a pair lives in the registers of one wavefront (qk_sweep_wave_kernel); 16 waves per CU
     const int wgrid = (int)std::min<long long>(np, 16ll * c->num_cus);
     qk_sweep_wave_kernel<0><<<dim3(wgrid), dim3(64), 0, c->stream>>>(a);
-    c->last.grid = wgrid;
+    launched_grid = wgrid, c->last.kernel = QK_KERNEL_WAVE;
   } else if (!fused && c->variant == 20 && c->small_path && std::max(xs->max_pad, ys->max_pad) <= 32 && lds_small <= 80 * 1024) {
     // every bond <= 32: X and T stay in LDS, only the site tensors stream (qk_sweep_small_kernel); chains too long for
     // its LDS budget (several hundred sites) take the ring kernel below
     if (f32) qk_sweep_small_kernel<float><<<dim3(grid), dim3(512), lds_small, c->stream>>>(a);
     else qk_sweep_small_kernel<double><<<dim3(grid), dim3(512), lds_small, c->stream>>>(a);
+    c->last.kernel = QK_KERNEL_SMALL;
   } else if (fused) {
     // X in LDS, T in registers, site tensors read straight into MFMA fragments from the interleaved image
     for (const qk_mps_set* m : {xs, ys}) {
@@ -646,18 +754,26 @@ extern "C" int qk_gram_values(qk_ctx* c, const qk_mps_set* xs, const qk_mps_set*
     HIP_TRY(hipEventRecord(c->ev0, c->stream));        // the conversion above is not part of the sweep
     if (fused_two) qk_sweep_fused_kernel<4, QKF_SLOTS, QKF_XCAP_TWO><<<dim3(grid), dim3(256), lds_fused, c->stream>>>(a);
     else qk_sweep_fused_kernel<8, QKF_SLOTS, QKF_XCAP_ONE><<<dim3(grid), dim3(512), lds_fused, c->stream>>>(a);
+    c->last.kernel = fused_two ? QK_KERNEL_FUSED2 : QK_KERNEL_FUSED1;
   } else if (f32) {  // complex64 sweep: the ring kernel on fp32 planes; QK_VARIANT does not apply
     qk_sweep_ring_kernel<float><<<dim3(grid), dim3(512), lds_ring, c->stream>>>(a);
+    c->last.kernel = QK_KERNEL_RING;
   } else if (c->variant == 20) {  // the shipped kernel: LDS-DMA staging ring (K-tile 8, three slots) + 3M complex product
     qk_sweep_ring_kernel<double><<<dim3(grid), dim3(512), lds_ring, c->stream>>>(a);
-  } else {  // experimental / diagnostic kernels (qk_lab.hip)
+    c->last.kernel = QK_KERNEL_RING;
+  } else {  // experimental / diagnostic kernels (qk_lab.hip, libqklab.so only)
+#ifdef QK_LAB
     const int rc_lab = qk_lab_launch(c, c->variant, a, grid, xs->n_sites);
     if (rc_lab != QK_OK) return rc_lab;
+    c->last.kernel = QK_KERNEL_LAB;
+#else
+    return fail(QK_EINVAL, "qk_gram_values: no kernel for this call");
+#endif
   }
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipEventRecord(c->ev1, c->stream));
   c->ev_pending = true;
-  c->last.grid = grid;
+  c->last.grid = launched_grid;
   return QK_OK;
 }
 
@@ -666,19 +782,15 @@ extern "C" int qk_gram_values_host(qk_ctx* c, const qk_mps_set* xs, const qk_mps
   const int64_t np = qk_plan_num_pairs(plan);
   if (np == 0) return QK_OK;
   HIP_TRY(hipSetDevice(c->device));
-  double *d_vals = nullptr, *d_z = nullptr;
-  HIP_TRY(hipMalloc(&d_vals, (size_t)np * sizeof(double)));
-  if (z_host) HIP_TRY(hipMalloc(&d_z, (size_t)np * 2 * sizeof(double)));
-  int rc = qk_gram_values(c, xs, ys, plan, d_vals, d_z);
-  if (rc == QK_OK) {
-    hipError_t e = hipMemcpyAsync(values_host, d_vals, (size_t)np * sizeof(double), hipMemcpyDeviceToHost, c->stream);
-    if (e == hipSuccess && z_host) e = hipMemcpyAsync(z_host, d_z, (size_t)np * 2 * sizeof(double), hipMemcpyDeviceToHost, c->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-    if (e != hipSuccess) rc = fail(QK_EDEVICE, "qk_gram_values_host: copy back failed: %s", hipGetErrorString(e));
-  }
-  (void)hipFree(d_vals);
-  if (d_z) (void)hipFree(d_z);
-  return rc;
+  DevBuf vals, z;  // released on every exit path
+  HIP_TRY(vals.alloc((size_t)np * sizeof(double)));
+  if (z_host) HIP_TRY(z.alloc((size_t)np * 2 * sizeof(double)));
+  const int rc = qk_gram_values(c, xs, ys, plan, vals.as<double>(), z.as<double>());
+  if (rc != QK_OK) return rc;
+  HIP_TRY(hipMemcpyAsync(values_host, vals.p, (size_t)np * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  if (z_host) HIP_TRY(hipMemcpyAsync(z_host, z.p, (size_t)np * 2 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return QK_OK;
 }
 
 extern "C" int qk_scatter(qk_ctx* c, const int32_t* pairs_dev, const double* values_dev, int64_t n, double* k_dev, int64_t ld, int32_t mirror) {
@@ -690,6 +802,20 @@ extern "C" int qk_scatter(qk_ctx* c, const int32_t* pairs_dev, const double* val
   HIP_TRY(hipGetLastError());
   return QK_OK;
 }
+
+extern "C" const char* qk_kernel_name(int32_t kernel, int32_t precision) {
+  const bool f32 = precision == 32;
+  switch (kernel) {
+    case QK_KERNEL_WAVE: return "qk_sweep_wave_kernel<0>";
+    case QK_KERNEL_SMALL: return f32 ? "qk_sweep_small_kernel<float>" : "qk_sweep_small_kernel<double>";
+    case QK_KERNEL_FUSED1: return "qk_sweep_fused_kernel<8, 4, 8192>";
+    case QK_KERNEL_FUSED2: return "qk_sweep_fused_kernel<4, 4, 4608>";
+    case QK_KERNEL_RING: return f32 ? "qk_sweep_ring_kernel<float>" : "qk_sweep_ring_kernel<double>";
+    case QK_KERNEL_LAB: return "(lab kernel)";
+    default: return "(none)";
+  }
+}
+static_assert(QKF_SLOTS == 4 && QKF_XCAP_ONE == 8192 && QKF_XCAP_TWO == 4608, "qk_kernel_name spells the fused sweep's template arguments");
 
 extern "C" int qk_get_stats(qk_ctx* c, qk_stats* out) {
   if (!c || !out) return fail(QK_EINVAL, "qk_get_stats: null argument");
@@ -712,63 +838,56 @@ static int plan_for_sets(const qk_mps_set* xs, const qk_mps_set* ys, qk_plan** p
                         sym ? nullptr : ys->dims_true.data(), sym ? QK_PLAN_SYMMETRIC : 0u, 1, 0, 0, plan);
 }
 
+struct PlanGuard {  // a plan owned by one call
+  qk_plan* p = nullptr;
+  ~PlanGuard() { qk_plan_destroy(p); }
+};
+
 extern "C" int qk_gram_host(qk_ctx* c, const qk_mps_set* xs, const qk_mps_set* ys, double* out, int64_t ld) {
   if (!c || !xs || !out) return fail(QK_EINVAL, "qk_gram_host: null argument");
   const bool sym = (ys == nullptr || ys == xs);
   const int nx = xs->n_states, ny = sym ? nx : ys->n_states;
   if (ld < nx) return fail(QK_EINVAL, "qk_gram_host: ld %lld < %d columns", (long long)ld, nx);
-  qk_plan* plan = nullptr;
-  int rc = plan_for_sets(xs, ys, &plan);
+  PlanGuard plan;
+  int rc = plan_for_sets(xs, ys, &plan.p);
   if (rc != QK_OK) return rc;
-  const int64_t np = qk_plan_num_pairs(plan);
-  double *d_vals = nullptr, *d_k = nullptr;
+  const int64_t np = qk_plan_num_pairs(plan.p);
+  DevBuf vals, k;
   HIP_TRY(hipSetDevice(c->device));
-  HIP_TRY(hipMalloc(&d_vals, (size_t)np * sizeof(double)));
-  HIP_TRY(hipMalloc(&d_k, (size_t)ny * nx * sizeof(double)));
-  HIP_TRY(hipMemsetAsync(d_k, 0, (size_t)ny * nx * sizeof(double), c->stream));
-  rc = qk_gram_values(c, xs, ys, plan, d_vals, nullptr);
-  if (rc == QK_OK) rc = qk_scatter(c, plan->d_pairs, d_vals, np, d_k, nx, sym ? 1 : 0);
-  if (rc == QK_OK) {
-    hipError_t e = hipMemcpy2DAsync(out, (size_t)ld * sizeof(double), d_k, (size_t)nx * sizeof(double), (size_t)nx * sizeof(double), (size_t)ny, hipMemcpyDeviceToHost, c->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-    if (e != hipSuccess) rc = fail(QK_EDEVICE, "qk_gram_host: copy back failed: %s", hipGetErrorString(e));
-  }
-  (void)hipFree(d_vals);
-  (void)hipFree(d_k);
-  qk_plan_destroy(plan);
-  return rc;
+  HIP_TRY(vals.alloc((size_t)np * sizeof(double)));
+  HIP_TRY(k.alloc((size_t)ny * nx * sizeof(double)));
+  HIP_TRY(hipMemsetAsync(k.p, 0, (size_t)ny * nx * sizeof(double), c->stream));
+  rc = qk_gram_values(c, xs, ys, plan.p, vals.as<double>(), nullptr);
+  if (rc == QK_OK) rc = qk_scatter(c, plan.p->d_pairs, vals.as<double>(), np, k.as<double>(), nx, sym ? 1 : 0);
+  if (rc != QK_OK) return rc;
+  HIP_TRY(hipMemcpy2DAsync(out, (size_t)ld * sizeof(double), k.p, (size_t)nx * sizeof(double), (size_t)nx * sizeof(double), (size_t)ny, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return QK_OK;
 }
 
 extern "C" int qk_overlaps_host(qk_ctx* c, const qk_mps_set* xs, const qk_mps_set* ys, double* out) {
   if (!c || !xs || !out) return fail(QK_EINVAL, "qk_overlaps_host: null argument");
   if (!ys) ys = xs;
   const int nx = xs->n_states, ny = ys->n_states;
-  qk_plan* plan = nullptr;  // all ny*nx pairs (no symmetry: z[i][j] = conj z[j][i] is left to the caller)
-  int rc = qk_plan_create(xs->n_sites, nx, xs->dims_true.data(), ny, ys->dims_true.data(), 0u, 1, 0, 16, &plan);
+  PlanGuard plan;  // all ny*nx pairs (no symmetry: z[i][j] = conj z[j][i] is left to the caller)
+  int rc = qk_plan_create(xs->n_sites, nx, xs->dims_true.data(), ny, ys->dims_true.data(), 0u, 1, 0, 16, &plan.p);
   if (rc != QK_OK) return rc;
-  const int64_t np = qk_plan_num_pairs(plan);
-  double *d_vals = nullptr, *d_z = nullptr;
+  const int64_t np = qk_plan_num_pairs(plan.p);
+  DevBuf vals, zd;
   HIP_TRY(hipSetDevice(c->device));
-  HIP_TRY(hipMalloc(&d_vals, (size_t)np * sizeof(double)));
-  HIP_TRY(hipMalloc(&d_z, (size_t)np * 2 * sizeof(double)));
-  rc = qk_gram_values(c, xs, ys, plan, d_vals, d_z);
+  HIP_TRY(vals.alloc((size_t)np * sizeof(double)));
+  HIP_TRY(zd.alloc((size_t)np * 2 * sizeof(double)));
+  rc = qk_gram_values(c, xs, ys, plan.p, vals.as<double>(), zd.as<double>());
+  if (rc != QK_OK) return rc;
   std::vector<double> z((size_t)np * 2);
-  if (rc == QK_OK) {
-    hipError_t e = hipMemcpyAsync(z.data(), d_z, z.size() * sizeof(double), hipMemcpyDeviceToHost, c->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-    if (e != hipSuccess) rc = fail(QK_EDEVICE, "qk_overlaps_host: copy back failed: %s", hipGetErrorString(e));
+  HIP_TRY(hipMemcpyAsync(z.data(), zd.p, z.size() * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  const int32_t* pr = qk_plan_pairs(plan.p);
+  for (int64_t t = 0; t < np; ++t) {
+    const int64_t o = ((int64_t)pr[2 * t + 1] * nx + pr[2 * t]) * 2;
+    out[o] = z[2 * t], out[o + 1] = z[2 * t + 1];
   }
-  if (rc == QK_OK) {
-    const int32_t* pr = qk_plan_pairs(plan);
-    for (int64_t t = 0; t < np; ++t) {
-      const int64_t o = ((int64_t)pr[2 * t + 1] * nx + pr[2 * t]) * 2;
-      out[o] = z[2 * t], out[o + 1] = z[2 * t + 1];
-    }
-  }
-  (void)hipFree(d_vals);
-  (void)hipFree(d_z);
-  qk_plan_destroy(plan);
-  return rc;
+  return QK_OK;
 }
 
 extern "C" int qk_selftest_mfma(qk_ctx* c) {
@@ -786,34 +905,34 @@ extern "C" int qk_selftest_mfma(qk_ctx* c) {
       for (int k = 0; k < 16; ++k) s += hp[k * 16 + m] * hq[k * 16 + n];
       ref[m * 16 + n] = s;
     }
-  double *dp, *dq, *dc;
-  HIP_TRY(hipMalloc(&dp, sizeof hp));
-  HIP_TRY(hipMalloc(&dq, sizeof hq));
-  HIP_TRY(hipMalloc(&dc, sizeof hc));
+  DevBuf bp, bq, bc;
+  HIP_TRY(bp.alloc(sizeof hp));
+  HIP_TRY(bq.alloc(sizeof hq));
+  HIP_TRY(bc.alloc(sizeof hc));
+  double *dp = bp.as<double>(), *dq = bq.as<double>(), *dc = bc.as<double>();
   HIP_TRY(hipMemcpy(dp, hp, sizeof hp, hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(dq, hq, sizeof hq, hipMemcpyHostToDevice));
   hipLaunchKernelGGL(qk_selftest_kernel, dim3(1), dim3(64), 0, c->stream, dp, dq, dc);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipStreamSynchronize(c->stream));
   HIP_TRY(hipMemcpy(hc, dc, sizeof hc, hipMemcpyDeviceToHost));
-  (void)hipFree(dp), (void)hipFree(dq), (void)hipFree(dc);
   double worst = 0;
   for (int e = 0; e < 256; ++e) worst = std::max(worst, std::fabs(hc[e] - ref[e]));
   if (worst > 1e-9) return fail(QK_EDEVICE, "qk_selftest_mfma: f64 MFMA fragment map mismatch (max abs error %.3g)", worst);
   // the same product through v_mfma_f32_16x16x4_f32 (operands are exact in fp32; sums of 16 such products too)
   float fp[256], fq[256], fc[256];
   for (int e = 0; e < 256; ++e) fp[e] = (float)hp[e], fq[e] = (float)hq[e];
-  float *ep, *eq, *ec;
-  HIP_TRY(hipMalloc(&ep, sizeof fp));
-  HIP_TRY(hipMalloc(&eq, sizeof fq));
-  HIP_TRY(hipMalloc(&ec, sizeof fc));
+  DevBuf be, bf, bg;
+  HIP_TRY(be.alloc(sizeof fp));
+  HIP_TRY(bf.alloc(sizeof fq));
+  HIP_TRY(bg.alloc(sizeof fc));
+  float *ep = be.as<float>(), *eq = bf.as<float>(), *ec = bg.as<float>();
   HIP_TRY(hipMemcpy(ep, fp, sizeof fp, hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(eq, fq, sizeof fq, hipMemcpyHostToDevice));
   hipLaunchKernelGGL(qk_selftest_f32_kernel, dim3(1), dim3(64), 0, c->stream, ep, eq, ec);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipStreamSynchronize(c->stream));
   HIP_TRY(hipMemcpy(fc, ec, sizeof fc, hipMemcpyDeviceToHost));
-  (void)hipFree(ep), (void)hipFree(eq), (void)hipFree(ec);
   worst = 0;
   for (int e = 0; e < 256; ++e) worst = std::max(worst, std::fabs((double)fc[e] - ref[e]));
   if (worst > 1e-3) return fail(QK_EDEVICE, "qk_selftest_mfma: f32 MFMA fragment map mismatch (max abs error %.3g)", worst);

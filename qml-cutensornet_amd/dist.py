@@ -77,3 +77,61 @@ def assemble_gram(ny: int, nx: int, pairs_by_rank, values_by_rank, symmetric: bo
         if symmetric:
             K[pairs[:, 0], pairs[:, 1]] = vals
     return K
+
+
+def exchange_sets(comm, ctx, local, lo: int, total: int, force_collective: bool = False):
+    """Every rank holds the whole data set after this: the replacement of the reference's ring of pickled MPS
+    (/root/reference/gpu_backend/kernel_state_ansatz.py:341-352, 415-419).  ``local`` is the device set of the
+    states [lo, lo + len(local)) this rank built (or ``None`` for an empty share).  The packed images are exchanged as
+    flat buffers -- ONE ``all_gather_into_tensor`` over RCCL when torch.distributed runs on nccl (nothing crosses PCIe),
+    the communicator's own ``allgather`` of the host images otherwise -- and assembled with ``qk_mps_set_from_packed``;
+    no state is re-packed element by element.  Returns (MpsSet of all ``total`` states, seconds in the exchange)."""
+    import time
+
+    size = comm.Get_size()
+    if size == 1 and not force_collective:  # (force_collective: the one-rank RCCL smoke test)
+        if local is None or len(local) != total:
+            raise RuntimeError("exchange_sets: a single rank must hold the whole set")
+        return local, 0.0
+    t0 = time.perf_counter()
+    if local is None:
+        n_loc, dims, offs = 0, np.zeros((0, 0), dtype=np.int32), np.zeros((0, 0), dtype=np.int64)
+    else:
+        n_loc, _, dims, offs = local.image()
+    meta = comm_allgather(comm, (int(lo), int(n_loc), dims, offs)) if size > 1 else [(int(lo), int(n_loc), dims, offs)]  # a few KB per rank
+    mx = max(1, max(m[1] for m in meta))
+    n_sites = max(m[2].shape[1] for m in meta) - 1
+    dims_all = np.zeros((total, n_sites + 1), dtype=np.int32)
+    offs_all = np.zeros((total, n_sites), dtype=np.int64)
+    for r, (lo_r, _, d_r, o_r) in enumerate(meta):
+        if d_r.shape[0]:
+            dims_all[lo_r : lo_r + d_r.shape[0]] = d_r
+            offs_all[lo_r : lo_r + d_r.shape[0]] = o_r + r * mx
+    if (dims_all[:, 0] != 1).any():
+        raise RuntimeError("exchange_sets left holes; ranks disagree on the data set size")
+    use_nccl = False
+    try:
+        import torch
+        import torch.distributed as dist
+
+        use_nccl = dist.is_initialized() and dist.get_world_size() == size and dist.get_backend() == "nccl"
+    except ImportError:
+        use_nccl = False
+    if use_nccl:
+        dev = torch.device("cuda", ctx.device_id)
+        send = torch.zeros(mx, dtype=torch.float64, device=dev)
+        if local is not None:
+            local.copy_image(send.data_ptr(), mx)
+        recv = torch.empty(size * mx, dtype=torch.float64, device=dev)
+        dist.all_gather_into_tensor(recv, send)
+        torch.cuda.synchronize(dev)
+        full = ctx.set_from_packed(dims_all, offs_all, recv.data_ptr(), size * mx)
+        del recv, send
+    else:  # host communicator (mpi4py, gloo): the packed HOST images travel; one upload of the joined buffer
+        mine = np.zeros(mx, dtype=np.float64)
+        if local is not None:
+            local.copy_image(mine.ctypes.data, mx)
+        parts = comm_allgather(comm, mine) if size > 1 else [mine]
+        joined = np.concatenate(parts)
+        full = ctx.set_from_packed(dims_all, offs_all, joined.ctypes.data, joined.shape[0])
+    return full, time.perf_counter() - t0

@@ -33,6 +33,8 @@ class QkStats(C.Structure):
         ("kernel_ms", C.c_double),
         ("grid", C.c_int32),
         ("max_bond", C.c_int32),
+        ("kernel", C.c_int32),
+        ("precision", C.c_int32),
     ]
 
     def as_dict(self):
@@ -54,6 +56,9 @@ _SIGNATURES = [
     ("qk_mps_set_create", C.c_int, [_P, C.c_int32, C.c_int32, _P, _P, C.c_int32, C.POINTER(_P)]),
     ("qk_mps_set_destroy", C.c_int, [_P]),
     ("qk_mps_set_info", C.c_int, [_P, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int64)]),
+    ("qk_mps_set_image", C.c_int, [_P, C.POINTER(C.c_int64), C.POINTER(_P), _P, _P]),
+    ("qk_mps_set_copy_image", C.c_int, [_P, _P, C.c_int64]),
+    ("qk_mps_set_from_packed", C.c_int, [_P, C.c_int32, C.c_int32, _P, _P, _P, C.c_int64, C.POINTER(_P)]),
     ("qk_mps_set_precision", C.c_int, [_P]),
     ("qk_mps_set_to_f32", C.c_int, [_P, _P, C.POINTER(_P)]),
     ("qk_pack_state_size", C.c_int64, [C.c_int32, _P]),
@@ -71,8 +76,7 @@ _SIGNATURES = [
     ("qk_gram_host", C.c_int, [_P, _P, _P, _P, C.c_int64]),
     ("qk_overlaps_host", C.c_int, [_P, _P, _P, _P]),
     ("qk_get_stats", C.c_int, [_P, C.POINTER(QkStats)]),
-    ("qk_debug_profile", C.c_int, [_P, _P]),
-    ("qk_debug_mma_bench", C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double)]),
+    ("qk_kernel_name", C.c_char_p, [C.c_int32, C.c_int32]),
     ("qk_selftest_mfma", C.c_int, [_P]),
     ("qk_build_mps", C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P, C.c_double, C.c_double, C.c_int32, C.c_uint32, C.POINTER(_P)]),
     ("qk_built_info", C.c_int, [_P, _P, _P, _P, C.POINTER(C.c_int64), C.POINTER(C.c_double)]),
@@ -82,6 +86,21 @@ _SIGNATURES = [
     ("qk_debug_jacobi", C.c_int, [_P, C.c_int32, C.c_int32, _P, _P, _P, _P]),
 ]
 EXPORTED_SYMBOLS = [s[0] for s in _SIGNATURES]
+# entry points of csrc/qk_lab.h: only the lab library (libqklab.so, loaded by tools/ via use_lab_library()) has them
+_LAB_SIGNATURES = [
+    ("qk_debug_profile", C.c_int, [_P, _P]),
+    ("qk_debug_mma_bench", C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double)]),
+]
+LAB_LIB_PATH = os.path.join(_HERE, "libqklab.so")
+
+
+def use_lab_library(path=None):
+    """tools/ only: load the lab library (experimental kernels, QK_VARIANT, instrumented builds) instead of the
+    shipped one.  Must be called before the first use of the engine."""
+    global LIB_PATH
+    if _lib is not None:
+        raise QkError("use_lab_library() must be called before the library is loaded")
+    LIB_PATH = path or os.environ.get("QK_LIB") or LAB_LIB_PATH
 
 
 def _preload_hip_runtime():
@@ -116,6 +135,10 @@ def lib():
         for name, res, args in _SIGNATURES:
             f = getattr(L, name)
             f.restype, f.argtypes = res, args
+        for name, res, args in _LAB_SIGNATURES:  # present in the lab library only
+            if hasattr(L, name):
+                f = getattr(L, name)
+                f.restype, f.argtypes = res, args
         _lib = L
     return _lib
 
@@ -228,6 +251,20 @@ class MpsSet:
         a, b, c, d = C.c_int32(), C.c_int32(), C.c_int32(), C.c_int64()
         _check(lib().qk_mps_set_info(self._h, C.byref(a), C.byref(b), C.byref(c), C.byref(d)), "qk_mps_set_info")
         return {"n_states": a.value, "n_sites": b.value, "max_padded_bond": c.value, "device_bytes": d.value}
+
+    def image(self):
+        """The fp64 device image of the set: (number of doubles, device address of the planes, true bonds
+        [n_states, n_sites + 1], re-plane offsets in doubles [n_states, n_sites])."""
+        n, ptr = C.c_int64(), _P()
+        ns, nsites = self.dims.shape[0], self.dims.shape[1] - 1
+        dims = np.zeros((ns, nsites + 1), dtype=np.int32)
+        offs = np.zeros((ns, nsites), dtype=np.int64)
+        _check(lib().qk_mps_set_image(self._h, C.byref(n), C.byref(ptr), dims.ctypes.data, offs.ctypes.data), "qk_mps_set_image")
+        return int(n.value), int(ptr.value or 0), dims, offs
+
+    def copy_image(self, dst_ptr: int, n_doubles: int):
+        """Copy the planes into a device or host buffer of ``n_doubles`` doubles (the send buffer of the all-gather)."""
+        _check(lib().qk_mps_set_copy_image(self._h, _P(dst_ptr), int(n_doubles)), "qk_mps_set_copy_image")
 
     @property
     def precision(self) -> int:
@@ -379,6 +416,66 @@ class Context:
             lib().qk_built_destroy(h)
         return MpsSet(self, hs, dims), {"kernel_ms": ms.value, "dims": dims, "fidelity": fid}
 
+    def set_from_packed(self, dims_true, offsets, planes_ptr: int, n_doubles: int) -> MpsSet:
+        """A set assembled from packed images (``MpsSet.image`` of several ranks, gathered into one buffer on the device or
+        on the host): see ``qk_mps_set_from_packed``."""
+        dims = np.ascontiguousarray(dims_true, dtype=np.int32)
+        offs = np.ascontiguousarray(offsets, dtype=np.int64)
+        h = _P()
+        _check(lib().qk_mps_set_from_packed(self._h, dims.shape[0], dims.shape[1] - 1, dims.ctypes.data, offs.ctypes.data, _P(planes_ptr), int(n_doubles), C.byref(h)),
+               "qk_mps_set_from_packed")
+        return MpsSet(self, h, dims)
+
+    def build_share(self, circuits, truncation_fidelity: float = 1.0 - 1e-16, value_of_zero: float = 1e-16, max_bond: int = 256, partial: bool = False):
+        """Device builder for one rank's share of a data set, the states staying on the device whenever possible: returns
+        (MpsSet, None, info) when every state fitted ``max_bond`` (packed on the device by ``qk_mps_set_from_built``: nothing
+        is downloaded), else (None, list[MPS | None], info) with the dropped states ``None`` (``partial`` only), to be
+        completed by the host builder.  info = {"kernel_ms", "dims", "fidelity", "dropped"}."""
+        from .mps import MPS
+
+        circuits = list(circuits)
+        if not circuits:
+            raise QkError("build_share needs at least one circuit")
+        c0 = circuits[0]
+        op = np.ascontiguousarray(c0.op, dtype=np.int8)
+        q0 = np.ascontiguousarray(c0.q0, dtype=np.int32)
+        for c in circuits[1:]:
+            if c.n_qubits != c0.n_qubits or not np.array_equal(c.op, c0.op) or not np.array_equal(c.q0, c0.q0):
+                raise QkError("build_share: the circuits of one call must share their gate structure")
+        alpha = np.ascontiguousarray(np.stack([np.asarray(c.alpha, dtype=np.float64) for c in circuits]))
+        n, ns = int(c0.n_qubits), len(circuits)
+        h = _P()
+        _check(lib().qk_build_mps(self._h, ns, n, int(op.shape[0]), op.ctypes.data, q0.ctypes.data, alpha.ctypes.data,
+                                  max(0.0, 1.0 - float(truncation_fidelity)), float(value_of_zero), int(max_bond), 1 if partial else 0, C.byref(h)), "qk_build_mps")
+        try:
+            dims = np.zeros((ns, n + 1), dtype=np.int32)
+            fid = np.zeros(ns, dtype=np.float64)
+            offs = np.zeros(ns, dtype=np.int64)
+            total, ms = C.c_int64(), C.c_double()
+            _check(lib().qk_built_info(h, dims.ctypes.data, fid.ctypes.data, offs.ctypes.data, C.byref(total), C.byref(ms)), "qk_built_info")
+            dropped = [int(k) for k in np.nonzero(fid < 0)[0]]
+            info = {"kernel_ms": ms.value, "dims": dims, "fidelity": fid, "dropped": dropped}
+            if not dropped:
+                hs = _P()
+                _check(lib().qk_mps_set_from_built(self._h, h, C.byref(hs)), "qk_mps_set_from_built")
+                return MpsSet(self, hs, dims), None, info
+            flat = np.empty(total.value, dtype=np.complex128)
+            _check(lib().qk_built_download(h, flat.ctypes.data), "qk_built_download")
+        finally:
+            lib().qk_built_destroy(h)
+        states = []
+        for s_ in range(ns):
+            if fid[s_] < 0:
+                states.append(None)
+                continue
+            pos, tensors = int(offs[s_]), []
+            for k in range(n):
+                sz = int(dims[s_, k]) * 2 * int(dims[s_, k + 1])
+                tensors.append(flat[pos : pos + sz].reshape(int(dims[s_, k]), 2, int(dims[s_, k + 1])))
+                pos += sz
+            states.append(MPS(tensors, float(fid[s_])))
+        return None, states, info
+
     def upload(self, states, layout=QK_LAYOUT_LPR) -> MpsSet:
         states = list(states)
         if not states:
@@ -438,7 +535,9 @@ class Context:
     def stats(self) -> dict:
         st = QkStats()
         _check(lib().qk_get_stats(self._h, C.byref(st)), "qk_get_stats")
-        return st.as_dict()
+        d = st.as_dict()
+        d["kernel_name"] = lib().qk_kernel_name(st.kernel, st.precision).decode()
+        return d
 
     def close(self):
         if self._h:

@@ -9,10 +9,12 @@ Surface kept (reference: /root/reference/gpu_backend/kernel_state_ansatz.py):
     same profiling-JSON keys (ref :160-162, 205, 238-244, 301-320, 434-444).
 
 What differs is how the work is done: the reference loops over pairs in Python and calls
-cuTensorNet once per entry, rotating pickled MPS between ranks; here every rank keeps all MPS
-on its MI355X, sweeps its share of the pairs in one persistent HIP kernel launch and the
-shares meet in a single all-gather (RCCL through torch.distributed when it is initialised with
-the nccl backend, the communicator's own ``allgather`` otherwise).
+cuTensorNet once per entry, rotating pickled MPS between ranks; here a rank builds its share of
+the states, keeps it as ONE packed device image, the images are exchanged as flat buffers (one
+RCCL all-gather, ``dist.exchange_sets``) so that every rank holds all MPS on its MI355X, each
+rank sweeps its share of the pairs in one persistent HIP kernel launch and the shares meet in a
+single all-gather (RCCL through torch.distributed when it is initialised with the nccl backend,
+the communicator's own ``allgather`` otherwise).
 """
 from __future__ import annotations
 
@@ -26,13 +28,13 @@ import numpy as np
 try:  # normal case: imported as qml_cutensornet_amd.gpu_backend.kernel_state_ansatz
     from ..ansatz import KernelStateAnsatz  # noqa: F401
     from .. import engine as _engine
-    from ..dist import assemble_gram, comm_allgather
+    from ..dist import assemble_gram, comm_allgather, exchange_sets
     from ..mps import MPS, simulate, simulate_many  # noqa: F401
 except ImportError:  # imported top-level as gpu_backend.kernel_state_ansatz
     import qml_cutensornet_amd as _pkg  # noqa: F401
     from qml_cutensornet_amd.ansatz import KernelStateAnsatz  # noqa: F401
     from qml_cutensornet_amd import engine as _engine
-    from qml_cutensornet_amd.dist import assemble_gram, comm_allgather
+    from qml_cutensornet_amd.dist import assemble_gram, comm_allgather, exchange_sets
     from qml_cutensornet_amd.mps import MPS, simulate, simulate_many  # noqa: F401
 
 ROOT_RANK = 0
@@ -44,14 +46,16 @@ def _say(is_root, text):
         sys.stdout.flush()
 
 
-def _simulate_share(ansatz, points, rank, n_procs, fidelity, is_root, label, device_id=0, host_workers=1):
-    """This rank's slice of the data set -> MPS (contiguous chunks of ceil(N/P), as ref :154,:171-174)."""
+def _simulate_share(ansatz, points, rank, n_procs, fidelity, is_root, label, device_id=0, host_workers=1, want_set=True):
+    """This rank's slice of the data set (contiguous chunks of ceil(N/P), as ref :154,:171-174) -> (first index, the
+    states as ONE packed device set -- ``None`` for an empty share --, seconds per state, fidelities).  ``want_set=False``
+    (host-only callers: the CPU tests) keeps the host builder's list of MPS instead of uploading it."""
     import os
 
     per_rank = -(-len(points) // n_procs)
     lo = min(len(points), rank * per_rank)
     hi = min(len(points), lo + per_rank)
-    which = os.environ.get("QK_BUILDER", "auto")  # auto | device | host
+    which = os.environ.get("QK_BUILDER", "auto") if want_set else "host"  # auto | device | host
     if which in ("device", "auto") and hi > lo:
         # the rank's whole share in ONE launch of the device builder (csrc/qk_build.hip): what the reference does with
         # simulate(libhandle, ...) on the rank's GPU (ref :221,:263).  Pays off at the small bonds of the reference's own
@@ -62,22 +66,25 @@ def _simulate_share(ansatz, points, rank, n_procs, fidelity, is_root, label, dev
         cap = int(os.environ.get("QK_BUILDER_MAX_BOND", "256" if which == "device" else "64"))
         circuits = [ansatz.circuit_for_data(points[k, :]) for k in range(lo, hi)]
         try:
-            states, binfo = _engine.default_context(device_id).build_mps(circuits, fidelity, max_bond=cap, partial=(which == "auto"))
+            dset, states, binfo = _engine.default_context(device_id).build_share(circuits, fidelity, max_bond=cap, partial=(which == "auto"))
         except _engine.QkError as exc:
             if which == "device":
                 raise
             _say(is_root, f"{label}: device builder gave up ({exc}); building on the host")
-            states = None
-        if states is not None:
+            dset, states, binfo = None, None, None
+        if binfo is not None:
             dt = (time.perf_counter() - t0) / (hi - lo)
             secs = [dt] * (hi - lo)
+            if dset is not None:  # every state fitted: the share is already a packed device set, nothing was downloaded
+                _say(is_root, f"{label}: 100%")
+                return lo, dset, secs, [float(f) for f in binfo["fidelity"]]
             if binfo["dropped"]:  # states whose bonds outgrew the cap: the host builder is the better tool for those
                 _say(is_root, f"{label}: {len(binfo['dropped'])} of {hi - lo} states outgrew bond {cap}; building them on the host")
                 built, bsecs = simulate_many([circuits[k] for k in binfo["dropped"]], fidelity, workers=host_workers)
                 for k, m, dt_k in zip(binfo["dropped"], built, bsecs):
                     states[k], secs[k] = m, dt_k
             _say(is_root, f"{label}: 100%")
-            return lo, states, secs
+            return lo, _engine.default_context(device_id).upload(states), secs, [m.fidelity for m in states]
     # host builder: one circuit per core on a thread pool (no fork: the GPU may already be initialised; the native builder
     # releases the GIL) -- the reference's loop is serial because its simulate() runs on the GPU (ref :213-231)
     tick, done = max(1, per_rank // 10), [0]
@@ -88,64 +95,51 @@ def _simulate_share(ansatz, points, rank, n_procs, fidelity, is_root, label, dev
             _say(is_root, f"{label}: {10 * ((done[0] - 1) // tick)}%")
 
     states, secs = simulate_many([ansatz.circuit_for_data(points[k, :]) for k in range(lo, hi)], fidelity, workers=host_workers, progress=progress)
-    return lo, states, secs
+    if not want_set:
+        return lo, states, secs, [m.fidelity for m in states]
+    if not states:
+        return lo, None, secs, []
+    return lo, _engine.default_context(device_id).upload(states), secs, [m.fidelity for m in states]
 
 
-def _gather_states(comm, lo, states, total):
-    """All-gather of the locally built MPS so that every rank holds the whole set."""
-    parts = comm_allgather(comm, (lo, [(m.tensors, m.fidelity) for m in states]))
-    full = [None] * total
-    for start, items in parts:
-        for off, (tensors, fid) in enumerate(items):
-            full[start + off] = MPS(tensors, fid)
-    if any(m is None for m in full):
-        raise RuntimeError("MPS all-gather left holes; ranks disagree on the data set size")
-    return full
-
-
-def _gram_on_device(comm, rank, n_procs, device_id, x_states, y_states):
+def _gram_on_device(comm, rank, n_procs, ctx, xset, yset):
     """The hot path.  Returns (K on the host or None, seconds in the final exchange)."""
-    ctx = _engine.Context(device_id)
-    try:
-        xset = ctx.upload(x_states)
-        yset = None if y_states is None else ctx.upload(y_states)
+    use_torch = False
+    if n_procs > 1:
         try:
+            import torch.distributed as dist
+
+            use_torch = dist.is_initialized() and dist.get_world_size() == n_procs and dist.get_backend() == "nccl"
+        except ImportError:
             use_torch = False
-            if n_procs > 1:
-                try:
-                    import torch.distributed as dist
+    if n_procs == 1:
+        return ctx.gram(xset, yset), 0.0
+    if use_torch:
+        import importlib
 
-                    use_torch = dist.is_initialized() and dist.get_world_size() == n_procs and dist.get_backend() == "nccl"
-                except ImportError:
-                    use_torch = False
-            if n_procs == 1:
-                return ctx.gram(xset, yset), 0.0
-            if use_torch:
-                import importlib
+        GramJob = importlib.import_module("qml_cutensornet_amd.gram").GramJob
 
-                GramJob = importlib.import_module("qml_cutensornet_amd.gram").GramJob
+        job = GramJob(ctx, xset, yset, n_procs, rank)
+        t0 = time.perf_counter()
+        K = job.run()
+        job.close()
+        return K, time.perf_counter() - t0
+    # host communicator (mpi4py or gloo): sweep on the GPU, all-gather the packed values on the host
+    plan = _engine.Plan(xset.dims, None if yset is None else yset.dims, n_procs, rank)
+    vals = ctx.gram_values_host(xset, yset, plan)
+    t0 = time.perf_counter()
+    shares = comm_allgather(comm, (plan.pairs(), vals))
+    exchange = time.perf_counter() - t0
+    ny = len(xset) if yset is None else len(yset)
+    K = assemble_gram(ny, len(xset), [s[0] for s in shares], [s[1] for s in shares], yset is None)
+    plan.close()
+    return K, exchange
 
-                job = GramJob(ctx, xset, yset, n_procs, rank)
-                t0 = time.perf_counter()
-                K = job.run()
-                job.close()
-                return K, time.perf_counter() - t0
-            # host communicator (mpi4py or gloo): sweep on the GPU, all-gather the packed values on the host
-            plan = _engine.Plan(xset.dims, None if yset is None else yset.dims, n_procs, rank)
-            vals = ctx.gram_values_host(xset, yset, plan)
-            t0 = time.perf_counter()
-            shares = comm_allgather(comm, (plan.pairs(), vals))
-            exchange = time.perf_counter() - t0
-            ny = len(x_states) if y_states is None else len(y_states)
-            K = assemble_gram(ny, len(x_states), [s[0] for s in shares], [s[1] for s in shares], y_states is None)
-            plan.close()
-            return K, exchange
-        finally:
-            xset.close()
-            if yset is not None:
-                yset.close()
-    finally:
-        ctx.close()
+
+def _set_mib(dims):
+    """MiB of the complex128 tensors of the states with bond table ``dims`` (what the reference sums from .nbytes, ref :295)."""
+    d = np.asarray(dims, dtype=np.float64)
+    return float((32.0 * d[:, :-1] * d[:, 1:]).sum() / 2**20)
 
 
 def build_kernel_matrix(mpi_comm, ansatz, X, Y=None, info_file=None, truncation_error=None, loglevel=30):
@@ -181,41 +175,52 @@ def build_kernel_matrix(mpi_comm, ansatz, X, Y=None, info_file=None, truncation_
     # circuits are bound lazily inside the simulation loop; the reference times their generation apart
     prof["r0_circ_gen"] = [0.0, "seconds"]
     _say(is_root, "\nContracting the MPS of the circuits from the X dataset...")
-    x_lo, x_mine, x_secs = _simulate_share(ansatz, X, rank, n_procs, fidelity, is_root, "X", device_id, host_workers)
-    y_lo, y_mine, y_secs = (0, [], [])
+    ctx = _engine.default_context(device_id)
+    x_lo, x_local, x_secs, x_fid = _simulate_share(ansatz, X, rank, n_procs, fidelity, is_root, "X", device_id, host_workers)
+    y_lo, y_local, y_secs, y_fid = (0, None, [], [])
     if Y is not None:
         _say(is_root, "\nContracting the MPS of the circuits from the Y dataset...")
-        y_lo, y_mine, y_secs = _simulate_share(ansatz, Y, rank, n_procs, fidelity, is_root, "Y", device_id, host_workers)
+        y_lo, y_local, y_secs, y_fid = _simulate_share(ansatz, Y, rank, n_procs, fidelity, is_root, "Y", device_id, host_workers)
     sim_secs = x_secs + y_secs
 
-    t0 = time.perf_counter()
-    x_states = _gather_states(mpi_comm, x_lo, x_mine, len(X))
-    y_states = None if Y is None else _gather_states(mpi_comm, y_lo, y_mine, len(Y))
-    gather_secs = time.perf_counter() - t0
+    # every rank gets the whole set: the packed device images of the shares, one all-gather (ref :341-352, 415-419)
+    xset, gather_secs = exchange_sets(mpi_comm, ctx, x_local, x_lo, len(X))
+    yset = None
+    if Y is not None:
+        yset, dt = exchange_sets(mpi_comm, ctx, y_local, y_lo, len(Y))
+        gather_secs += dt
+    for loc, full in ((x_local, xset), (y_local, yset)):
+        if loc is not None and loc is not full:
+            loc.close()
 
-    if is_root:
-        mine = x_mine + y_mine
-        prof["r0_circ_sim"] = [sum(sim_secs), "seconds"]
-        if sim_secs:
-            prof["avg_circ_sim"] = [mean(sim_secs), "seconds"]
-            prof["median_circ_sim"] = [median(sim_secs), "seconds"]
-            prof["q1_circ_sim"] = [float(np.percentile(sim_secs, 25)), "seconds"]
-            prof["q3_circ_sim"] = [float(np.percentile(sim_secs, 75)), "seconds"]
-        everything = x_states + ([] if y_states is None else y_states)
-        total_mib = sum(m.nbytes() for m in everything) / 2**20
-        prof["gpu_mps_mem"] = [total_mib, "MiB"]  # every GPU holds the whole set here
-        prof["avg_mps_mem"] = [total_mib / len(everything), "MiB"]
-        prof["avg_fidelity"] = [sum(m.fidelity for m in mine) / max(1, len(mine)), ""]
-        chi_x = [m.max_bond() for m in x_states]
-        prof["ave max chi x"] = (mean(chi_x), "chi x")
-        prof["ave max chi y"] = (mean(chi_x if y_states is None else [m.max_bond() for m in y_states]), "chi y")
-        prof["r_nonRR_recv"] = [0, "seconds"]  # no ranks outside a ring: there is no ring
-        prof["r0_RR_recv"] = [gather_secs, "seconds"]  # MPS all-gather; the Gram all-gather is added below
-        _say(True, "\nFinished contracting all MPS.\n\nCalculating kernel matrix...")
+    try:
+        if is_root:
+            mine_fid = x_fid + y_fid
+            prof["r0_circ_sim"] = [sum(sim_secs), "seconds"]
+            if sim_secs:
+                prof["avg_circ_sim"] = [mean(sim_secs), "seconds"]
+                prof["median_circ_sim"] = [median(sim_secs), "seconds"]
+                prof["q1_circ_sim"] = [float(np.percentile(sim_secs, 25)), "seconds"]
+                prof["q3_circ_sim"] = [float(np.percentile(sim_secs, 75)), "seconds"]
+            total_mib = _set_mib(xset.dims) + (0.0 if yset is None else _set_mib(yset.dims))
+            n_all = len(xset) + (0 if yset is None else len(yset))
+            prof["gpu_mps_mem"] = [total_mib, "MiB"]  # every GPU holds the whole set here
+            prof["avg_mps_mem"] = [total_mib / n_all, "MiB"]
+            prof["avg_fidelity"] = [sum(mine_fid) / max(1, len(mine_fid)), ""]
+            chi_x = xset.dims.max(axis=1)
+            prof["ave max chi x"] = (float(chi_x.mean()), "chi x")
+            prof["ave max chi y"] = (float((chi_x if yset is None else yset.dims.max(axis=1)).mean()), "chi y")
+            prof["r_nonRR_recv"] = [0, "seconds"]  # no ranks outside a ring: there is no ring
+            prof["r0_RR_recv"] = [gather_secs, "seconds"]  # exchange of the packed sets; the Gram all-gather is added below
+            _say(True, "\nFinished contracting all MPS.\n\nCalculating kernel matrix...")
 
-    t_tiles = time.perf_counter()
-    kernel_mat, exchange = _gram_on_device(mpi_comm, rank, n_procs, device_id, x_states, y_states)
-    tiles = time.perf_counter() - t_tiles
+        t_tiles = time.perf_counter()
+        kernel_mat, exchange = _gram_on_device(mpi_comm, rank, n_procs, ctx, xset, yset)
+        tiles = time.perf_counter() - t_tiles
+    finally:
+        xset.close()
+        if yset is not None:
+            yset.close()
 
     if not is_root:
         return None

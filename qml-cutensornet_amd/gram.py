@@ -19,9 +19,11 @@ class GramJob:
     """Reusable plan + buffers for one (xset, yset) Gram on this rank's GPU."""
 
     def __init__(self, ctx: engine.Context, xset: engine.MpsSet, yset: engine.MpsSet | None = None,
-                 world_size: int = 1, rank: int = 0, group=None, block: int | None = None):
+                 world_size: int = 1, rank: int = 0, group=None, block: int | None = None, force_collective: bool = False):
         self.ctx, self.xset, self.yset = ctx, xset, yset
         self.world, self.rank, self.group = int(world_size), int(rank), group
+        # force_collective: run the all-gathers even in a one-rank group (the RCCL smoke test: tests/test_gpu_nccl.py)
+        self.collective = self.world > 1 or bool(force_collective)
         self.symmetric = yset is None
         import os
 
@@ -30,24 +32,30 @@ class GramJob:
         self.nx = len(xset)
         self.ny = self.nx if self.symmetric else len(yset)
         ydims = None if self.symmetric else yset.dims
-        quads = os.environ.get("QK_QUADS", "0") == "1"  # 2x2 pair blocks per workgroup (QK_PLAN_QUADS)
+        quads = os.environ.get("QK_QUADS", "0") == "1"  # 2x2 pair blocks per workgroup (QK_PLAN_QUADS): tools/ with the lab library only
         self.plan = engine.Plan(xset.dims, ydims, self.world, self.rank, block, quads)
         self.maxp = max(1, self.plan.max_pairs_per_rank)
         dev = torch.device("cuda", ctx.device_id)
         self.dev = dev
-        # pair table of ALL ranks (plans are deterministic host objects), padded with -1
-        table = np.full((self.world, self.maxp, 2), -1, dtype=np.int32)
-        self.work = []
-        for r in range(self.world):
-            p = self.plan if r == self.rank else engine.Plan(xset.dims, ydims, self.world, r, block, quads)
-            pr = p.pairs()
-            table[r, : pr.shape[0]] = pr
-            self.work.append(p.stats())
-            if p is not self.plan:
-                p.close()
-        self.all_pairs = torch.from_numpy(table.reshape(-1, 2)).to(dev)
+        # pair table of ALL ranks, padded with -1: each rank contributes the pairs of its own plan (one small all-gather at
+        # set-up; the plans are deterministic, but building P plans on every rank costs P times the planning time)
+        pr = self.plan.pairs()
+        mine = np.full((self.maxp, 2), -1, dtype=np.int32)
+        mine[: pr.shape[0]] = pr
+        self.work = {self.rank: self.plan.stats()}  # algorithmic work of THIS rank's share
+        my_pairs = torch.from_numpy(mine).to(dev)
+        if self.collective:
+            import torch.distributed as dist
+
+            self.all_pairs = torch.empty((self.world * self.maxp, 2), dtype=torch.int32, device=dev)
+            if dist.get_backend(self.group) == "nccl":
+                dist.all_gather_into_tensor(self.all_pairs, my_pairs, group=self.group)
+            else:
+                dist.all_gather(list(self.all_pairs.view(self.world, self.maxp, 2).unbind(0)), my_pairs, group=self.group)
+        else:
+            self.all_pairs = my_pairs
         self.my_vals = torch.zeros(self.maxp, dtype=torch.float64, device=dev)
-        self.all_vals = torch.zeros(self.world * self.maxp, dtype=torch.float64, device=dev) if self.world > 1 else self.my_vals
+        self.all_vals = torch.zeros(self.world * self.maxp, dtype=torch.float64, device=dev) if self.collective else self.my_vals
         self.K = torch.zeros((self.ny, self.nx), dtype=torch.float64, device=dev)
 
     def enqueue(self) -> torch.Tensor:
@@ -55,7 +63,7 @@ class GramJob:
         stream = torch.cuda.current_stream(self.dev)
         self.ctx.set_stream(stream.cuda_stream)
         self.ctx.gram_values(self.xset, self.yset, self.plan, self.my_vals.data_ptr())
-        if self.world > 1:
+        if self.collective:
             import torch.distributed as dist
 
             if dist.get_backend(self.group) == "nccl":  # RCCL over xGMI: the one collective of the path

@@ -31,10 +31,14 @@ def _worker(rank, world, port, q):
         X = R.synthetic_features(9, n, 2)
         ans = Q.KernelStateAnsatz(n, 2, 1.0, Q.entanglement_graph(n, 2))
         # each rank builds its contiguous share, then everybody gets everything (as build_kernel_matrix does)
-        from qml_cutensornet_amd.gpu_backend.kernel_state_ansatz import _gather_states, _simulate_share
+        from qml_cutensornet_amd.gpu_backend.kernel_state_ansatz import _simulate_share
+        from qml_cutensornet_amd.mps import MPS
 
-        lo, mine, _ = _simulate_share(ans, X, rank, world, 1 - 1e-16, False, "X")
-        states = _gather_states(comm, lo, mine, len(X))
+        lo, mine, _, _ = _simulate_share(ans, X, rank, world, 1 - 1e-16, False, "X", want_set=False)
+        states = [None] * len(X)  # (on a GPU the shares travel as packed device images: dist.exchange_sets, tests/test_gpu_nccl.py)
+        for start, items in comm_allgather(comm, (lo, [m.tensors for m in mine])):
+            for off, tensors in enumerate(items):
+                states[start + off] = MPS(tensors)
         dims = np.stack([m.bond_dims() for m in states])
         out = {}
         for sym in (True, False):

@@ -1,0 +1,90 @@
+"""RCCL on the one GPU of the test box, and a 4-rank rehearsal of the multi-GPU bench.
+
+The driver's 8-GPU node is the only place where the nccl branches run with more than one rank.  What can be run here:
+(1) a ONE-rank nccl process group that pushes GramJob and the packed-set exchange through ``all_gather_into_tensor``
+    (RCCL is loaded, the communicator is created, the collective calls execute on the GPU);
+(2) the bench itself with 4 ranks over gloo on GPU 0 (the GPU box admits 6 processes on its card: the test runner, the
+    launcher and four ranks): identical K on every rank, balanced shares.
+"""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _nccl_worker(port, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch
+    import torch.distributed as dist
+
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        import qml_cutensornet_amd as Q
+        from qml_cutensornet_amd import engine
+        from qml_cutensornet_amd.dist import TorchComm, exchange_sets
+        from qml_cutensornet_amd.gram import GramJob
+
+        rng = np.random.default_rng(8)
+        prof = [1, 2, 4, 8, 16, 32, 40, 32, 16, 8, 4, 2, 1]
+        states = [Q.random_mps(12, prof, rng) for _ in range(9)]
+        ctx = engine.Context(0)
+        local = ctx.upload(states)
+        # the packed-set exchange through RCCL all_gather_into_tensor (one rank: the gathered image is the local one)
+        full, secs = exchange_sets(TorchComm(), ctx, local, 0, len(states), force_collective=True)
+        job = GramJob(ctx, full, None, 1, 0, force_collective=True)  # all_gather_into_tensor of pairs and of values
+        K = job.run()
+        K_plain = ctx.gram(local)
+        q.put({"K": K, "K_plain": K_plain, "backend": dist.get_backend(), "states": [m.tensors for m in states], "exchange_s": secs})
+        job.close(), full.close(), local.close(), ctx.close()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_one_rank_nccl_group_runs_the_collectives(built):
+    import torch.multiprocessing as mp
+
+    from oracle import restatement as R
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_nccl_worker, args=(29500 + (os.getpid() % 400), q))
+    p.start()
+    res = q.get(timeout=240)
+    p.join(60)
+    assert p.exitcode == 0
+    assert res["backend"] == "nccl"
+    ref = R.gram_from_mps(res["states"])
+    assert np.abs(res["K"] - ref).max() < 1e-11
+    # the gathered set and the gathered values change nothing (two launches of the fused sweep may differ in the last bit:
+    # the sum over the tiles of a column is taken by LDS atomics, in arrival order)
+    assert np.abs(res["K"] - res["K_plain"]).max() < 1e-14
+
+
+@pytest.mark.timeout(900)
+def test_four_rank_bench_rehearsal(built, tmp_path):
+    """bench.py --gpus 4 on GPU 0 over gloo (QK_FORCE_DEVICE / QK_DIST_BACKEND are the bench's rehearsal hooks): 120 points of
+    cfg4.  Every rank must end with the same K and the ranks' shares of the padded work must be equal."""
+    env = dict(os.environ, QK_FORCE_DEVICE="0", QK_DIST_BACKEND="gloo", QK_CACHE_DIR=str(tmp_path / "cache"), MASTER_ADDR="127.0.0.1")
+    port = 29900 + (os.getpid() % 90)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "4", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(ROOT, "bench.py"), "--gpus", "4", "--points", "120", "--steps", "2", "--warmup", "1", "--cpu-seconds", "0"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=800, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == 4 and d["config"]["unique_pairs"] == 120 * 121 // 2
+    assert d["config"]["k_identical_on_all_ranks"] is True
+    assert d["config"]["diag_err"] < 1e-11 and d["config"]["sym_err"] == 0.0
+    ms, work = np.array(d["config"]["rank_kernel_ms"]), np.array(d["config"]["rank_padded_tflop"])
+    assert len(ms) == 4 and ms.min() > 0  # (four processes time-share ONE GPU here: their kernel times say nothing about balance)
+    assert work.max() / work.min() < 1.01, work  # the serpentine deal of the cost-ordered pairs: equal shares of the padded work

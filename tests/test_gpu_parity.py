@@ -9,6 +9,9 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 TOL = 1e-11
+# Two launches on the same inputs may differ in the last bits: the site-fused sweep sums the tiles of a column of X' with
+# LDS atomics (ds_add_f64), i.e. in arrival order.  Entries are <= 1, so this is an absolute bound of a few ulp.
+LAUNCH_EPS = 1e-14
 
 
 def _ragged_profile(rng, n, chi_max):
@@ -144,7 +147,7 @@ def test_rank_shares_reassemble(gpu_ctx, world):
             K = assemble_gram(len(xs) if sym else len(ys), len(xs), pairs, vals, sym)
             ref = R.gram_from_mps([m.tensors for m in xs], None if sym else [m.tensors for m in ys])
             assert np.abs(K - ref).max() < TOL
-            assert np.array_equal(K, gpu_ctx.gram(dx, None if sym else dy))  # bit-identical to the 1-rank path
+            assert np.abs(K - gpu_ctx.gram(dx, None if sym else dy)).max() < 1e-14  # the 1-rank path (see LAUNCH_EPS below)
 
 
 def test_gram_job_device_path(gpu_ctx):
@@ -163,7 +166,7 @@ def test_gram_job_device_path(gpu_ctx):
             job.close()
     finally:
         gpu_ctx.set_stream(None)  # back to the context's private stream for the other tests
-    assert np.array_equal(K, K2)
+    assert np.abs(K - K2).max() < LAUNCH_EPS
     assert np.abs(K - R.gram_from_mps([m.tensors for m in xs])).max() < TOL
 
 
@@ -279,7 +282,7 @@ def test_host_layout_lrp(gpu_ctx):
             return len(self._m)
 
     with gpu_ctx.upload(xs) as a, gpu_ctx.upload([Swapped(m) for m in xs], layout=engine.QK_LAYOUT_LRP) as b:
-        assert np.array_equal(gpu_ctx.gram(a), gpu_ctx.gram(b))
+        assert np.abs(gpu_ctx.gram(a) - gpu_ctx.gram(b)).max() < LAUNCH_EPS
 
 
 def test_bad_inputs_fail_loudly(gpu_ctx):
@@ -340,32 +343,20 @@ def test_f32_gram_of_ansatz_states(gpu_ctx):
     assert np.abs(K32 - K32.T).max() == 0.0
 
 
-# ------------------------------------------------------------------ 2x2 pair blocks (QK_PLAN_QUADS)
-@pytest.mark.parametrize("n,chi_max,nx,ny,seed", [(6, 4, 3, 2, 1), (14, 40, 4, 5, 3), (16, 100, 3, 4, 4), (18, 150, 5, 2, 5)])
-def test_quad_plan_matches_oracle(gpu_ctx, n, chi_max, nx, ny, seed):
+# ------------------------------------------------------------------ 2x2 pair blocks (QK_PLAN_QUADS): lab library only
+def test_quad_plans_are_refused_by_the_product_library(gpu_ctx):
+    """QK_PLAN_QUADS plans are swept by an experimental kernel that only libqklab.so (tools/) contains: the shipped
+    library must say so instead of running anything."""
     import qml_cutensornet_amd as Q
     from qml_cutensornet_amd import engine
-    from oracle import restatement as R
 
-    rng = np.random.default_rng(seed)
-    xs = [Q.random_mps(n, _ragged_profile(rng, n, chi_max), rng) for _ in range(nx)]
-    ys = [Q.random_mps(n, _ragged_profile(rng, n, chi_max), rng) for _ in range(ny)]
-    z_ref = np.array([[R.mps_inner(x.tensors, y.tensors) for x in xs] for y in ys])
-    zs_ref = np.array([[R.mps_inner(x.tensors, y.tensors) for x in xs] for y in xs])
-    with gpu_ctx.upload(xs) as dx, gpu_ctx.upload(ys) as dy:
-        for sym in (False, True):
-            plan = engine.Plan(dx.dims, None if sym else dy.dims, quads=True)
-            vals, z = gpu_ctx.gram_values_host(dx, None if sym else dy, plan, want_z=True)
-            ref = zs_ref if sym else z_ref
-            for (i, j), v, zz in zip(plan.pairs().tolist(), vals, z):
-                assert abs(zz - ref[j, i]) < TOL and abs(v - abs(ref[j, i]) ** 2) < TOL
-            plan.close()
-        with dx.to_f32() as fx, dy.to_f32() as fy:  # the quad kernel in complex64
-            plan = engine.Plan(dx.dims, dy.dims, quads=True)
-            vals, z = gpu_ctx.gram_values_host(fx, fy, plan, want_z=True)
-            for (i, j), zz in zip(plan.pairs().tolist(), z):
-                assert abs(zz - z_ref[j, i]) < F32_TOL
-            plan.close()
+    rng = np.random.default_rng(3)
+    xs = [Q.random_mps(10, _ragged_profile(rng, 10, 40), rng) for _ in range(4)]
+    with gpu_ctx.upload(xs) as dx:
+        plan = engine.Plan(dx.dims, None, quads=True)
+        with pytest.raises(engine.QkError, match="libqklab"):
+            gpu_ctx.gram_values_host(dx, None, plan)
+        plan.close()
 
 
 # ------------------------------------------------------------------ small-bond sweep (all bonds <= 32: X, T resident in LDS)

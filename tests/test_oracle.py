@@ -77,3 +77,21 @@ def test_c_restatement_agrees_with_numpy(built):
     v2, z2, _ = c_oracle.gram_pairs(xs, None, [(0, 0), (0, 1), (1, 1)], threads=1)
     assert abs(v2[0] - abs(R.mps_inner(xs[0], xs[0])) ** 2) < 1e-13
     assert abs(z2[1] - R.mps_inner(xs[0], xs[1])) < 1e-13
+
+
+def test_blas_leg_matches_hand_loop():
+    """oracle/overlap_blas.c (every contraction on zgemm: the CPU baseline of bench.py) against oracle/overlap_ref.c and
+    the numpy restatement on ragged MPS."""
+    import qml_cutensornet_amd as Q
+    from oracle import c_oracle
+
+    rng = np.random.default_rng(12)
+    n = 14
+    xs = [Q.random_mps(n, [min(2 ** min(k, n - k), c) for k in range(n + 1)], rng) for c in (3, 17, 40)]
+    ys = [Q.random_mps(n, [min(2 ** min(k, n - k), c) for k in range(n + 1)], rng) for c in (8, 33)]
+    pairs = np.array([(i, j) for j in range(2) for i in range(3)], dtype=np.int32)
+    v_ref, z_ref, _ = c_oracle.gram_pairs([m.tensors for m in xs], [m.tensors for m in ys], pairs)
+    v_blas, z_blas, _ = c_oracle.gram_pairs_blas([m.tensors for m in xs], [m.tensors for m in ys], pairs, threads=2)
+    z_np = np.array([R.mps_inner(xs[i].tensors, ys[j].tensors) for i, j in pairs])
+    assert np.abs(z_blas - z_ref).max() < 1e-13 and np.abs(z_blas - z_np).max() < 1e-13
+    assert np.abs(v_blas - np.abs(z_np) ** 2).max() < 1e-13

@@ -8,8 +8,8 @@ sys.path.insert(0, ROOT)
 import qml_cutensornet_amd  # noqa: F401
 from qml_cutensornet_amd import engine
 
-if "QK_LIB" in os.environ:  # before anything calls engine.lib()
-    engine.LIB_PATH = os.environ["QK_LIB"]
+if "QK_LIB" in os.environ or "QK_VARIANT" in os.environ:  # before anything calls engine.lib()
+    engine.use_lab_library()
 import bench
 
 bench.main()

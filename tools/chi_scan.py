@@ -12,8 +12,8 @@ import qml_cutensornet_amd as Q
 from qml_cutensornet_amd import engine
 
 PEAK = 256 * 4 * 32 * 2.4e9
-if "QK_LIB" in os.environ:  # experiment builds of the library (tools/exp_fused.sh)
-    engine.LIB_PATH = os.environ["QK_LIB"]
+if "QK_LIB" in os.environ or "QK_VARIANT" in os.environ:  # the lab library, or an experiment build of it (tools/exp_fused.sh)
+    engine.use_lab_library()
 
 
 def profile(n, chi):

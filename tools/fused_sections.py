@@ -7,8 +7,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 os.environ.setdefault("QK_FUSED", "2")
 import qml_cutensornet_amd as Q
 from qml_cutensornet_amd import engine
-if "QK_LIB" in os.environ:
-    engine.LIB_PATH = os.environ["QK_LIB"]
+engine.use_lab_library()  # $QK_LIB (an instrumented experiment build) or libqklab.so
 names = ["pair set-up", "X LDS<->global", "phase 1", "wait P1 + zero", "phase 2", "wait P2", "touch / strip zero", "wave lifetime"]
 ctx = engine.Context(0)
 if len(sys.argv) > 1:

@@ -1,6 +1,8 @@
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from qml_cutensornet_amd import engine
+
+engine.use_lab_library()  # the experimental kernels live in libqklab.so only
 ctx = engine.Context(0)
 names = ["bare MFMA block", "+ barrier per step", "+ LDS stash", "+ global fetch (1 step ahead)", "+ global fetch (2 steps ahead)", "  same, 1-ahead, from HBM stream", "  same, 2-ahead, from HBM stream"]
 for nw in (4, 8):

@@ -8,6 +8,8 @@ os.environ.setdefault("QK_VARIANT", "19")
 import qml_cutensornet_amd as Q
 from qml_cutensornet_amd import engine
 
+engine.use_lab_library()  # the experimental kernels live in libqklab.so only
+
 names = ["fetch issue", "MFMA block", "epilogue stores", "stash (+vmcnt wait)", "barrier", "phase prologue", "phase-end barrier", "wave lifetime"]
 ctx = engine.Context(0)
 if len(sys.argv) > 1:
