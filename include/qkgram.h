@@ -46,6 +46,12 @@ extern "C" {
                                 block (a symmetric plan's diagonal blocks include one mirrored pair i > j, an odd set's last
                                 block repeats its state): scatter handles both. */
 
+#define QK_PLAN_ORIENT 4u    /* symmetric plans only: a pair {i, j} is listed as (i, j) or as (j, i), whichever order of contraction is
+                                cheaper on the matrix cores (the sweep contracts the environment with the Y tensor first; which state
+                                plays Y decides the padded tile counts).  |<x_i|x_j>| = |<x_j|x_i>|, so K is unchanged and the optional z
+                                output is the overlap of the pair AS LISTED.  This is the host-side greedy choice of the contraction
+                                order (north star; reference call site G:380). */
+
 typedef struct qk_ctx qk_ctx;         /* one per device; replaces CuTensorNetHandle(device_id), G:213,255,366 */
 typedef struct qk_mps_set qk_mps_set; /* a device-resident list of MPS; replaces the per-rank lists of
                                          pytket-cutensornet MPS objects mps_x_chunk / mps_y_chunk, G:210,252,290 */

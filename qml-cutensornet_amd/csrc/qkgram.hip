@@ -124,10 +124,24 @@ static void pair_work(int n, const int32_t* a, const int32_t* b, double* flops, 
   *bytes = by + 8;
 }
 
+// Matrix instructions the site-fused sweep issues for the pair (x = a, y = b): per site (a^/16)(b'^/16) tiles of T, each
+// ceil(b/4) k-steps in phase 1 and (a'^/16) column blocks x ceil(a/4)-bounded k-steps in phase 2 (x 3 for the 3M product,
+// x 2 for p).  The ring sweep's padded flops follow the same asymmetry, so one model serves both.
+static double fused_cost(int n, const int32_t* a, const int32_t* b) {
+  double c = 0;
+  for (int k = 0; k < n; ++k) {
+    const double A0 = pad16(a[k]) / 16, A1 = pad16(a[k + 1]) / 16, B1 = pad16(b[k + 1]) / 16;
+    const double kb = (b[k] + 3) / 4, ka = (a[k] + 3) / 4;
+    c += 6 * A0 * B1 * kb + 6 * B1 * A1 * ka;
+  }
+  return c;
+}
+
 extern "C" int qk_plan_create(int32_t n_sites, int32_t nx, const int32_t* x_dims, int32_t ny, const int32_t* y_dims,
                               uint32_t flags, int32_t world_size, int32_t rank, int32_t block, qk_plan** out) {
   if (!out || !x_dims || n_sites <= 0 || nx <= 0) return fail(QK_EINVAL, "qk_plan_create: bad argument");
   const bool sym = (flags & QK_PLAN_SYMMETRIC) != 0;
+  const bool orient = sym && (flags & QK_PLAN_ORIENT) != 0 && !(flags & QK_PLAN_QUADS);
   if (sym) {
     y_dims = x_dims;
     ny = nx;
@@ -215,8 +229,11 @@ extern "C" int qk_plan_create(int32_t n_sites, int32_t nx, const int32_t* x_dims
         for (int i = bi * block; i < std::min(nx, (bi + 1) * block); ++i) {
           if (sym && i > j) continue;
           double f, fp, by;
-          pair_work(n_sites, x_dims + (int64_t)i * stride, y_dims + (int64_t)j * stride, &f, &fp, &by);
-          tile.push_back({i, j, (float)fp});
+          int xi = i, yj = j;  // the cheaper order of contraction: which state plays Y (QK_PLAN_ORIENT)
+          if (orient && i != j && fused_cost(n_sites, x_dims + (int64_t)j * stride, y_dims + (int64_t)i * stride) < fused_cost(n_sites, x_dims + (int64_t)i * stride, y_dims + (int64_t)j * stride))
+            xi = j, yj = i;
+          pair_work(n_sites, x_dims + (int64_t)xi * stride, y_dims + (int64_t)yj * stride, &f, &fp, &by);
+          tile.push_back({xi, yj, (float)fp});
         }
       std::stable_sort(tile.begin(), tile.end(), [](const Item& u, const Item& v) { return u.cost > v.cost; });
       for (const Item& it : tile) {
@@ -683,14 +700,17 @@ extern "C" int qk_gram_values(qk_ctx* c, const qk_mps_set* xs, const qk_mps_set*
   const long long units = quad ? np / 4 : grouped ? (long long)plan->groups.size() / 2 : (duo ? (np + 1) / 2 : np);
   const int max_pad = std::max(xs->max_pad, ys->max_pad);
   // the site-fused sweep (qk_fused.h), fp64.  Two shapes: one 8-wave workgroup per CU with an 8192-element X buffer, or two
-  // 4-wave workgroups with 4608 elements each (better when most of the work sits in sites that fit the smaller buffer: the
-  // second workgroup fills the first one's barriers).  A 16-row strip of X' must fit the buffer: bonds <= XCAP / 16.
+  // 4-wave workgroups with 4608 elements each.  The second workgroup fills the first one's barriers and per-site set-up
+  // (+24 % on the 40-qubit x 4-layer set), but every site that does not fit the smaller buffer runs in strips from a global
+  // X: on the 60-qubit x 6-layer headline set (57 % of the work fits) the two shapes are within 2 % in time while the
+  // smaller buffer moves 3.2 instead of 1.9 TB through the fabric -- so two workgroups only when >= 75 % of the padded
+  // work fits.  A 16-row strip of X' must fit the buffer: bonds <= XCAP / 16.
   const size_t lds_meta = 16 + (size_t)xs->n_sites * (48 + 16);  // queue slot, per-site records and tensor offsets
   const bool fused_ok = c->variant == 20 && !f32 && !quad && c->fused_path != 0 && max_pad > (c->fused_path >= 2 ? 16 : 32);
   const bool can_one = max_pad <= QKF_XCAP_ONE / TILE && (size_t)QKF_XCAP_ONE * 16 + lds_meta <= 160 * 1024;
   const bool can_two = max_pad <= QKF_XCAP_TWO / TILE && (size_t)QKF_XCAP_TWO * 16 + lds_meta <= 80 * 1024;
   const bool fused = fused_ok && (can_one || can_two);
-  const bool fused_two = fused && can_two && (!can_one || c->fused_wgs == 2 || (c->fused_wgs == 0 && plan->fit_two >= 0.4));
+  const bool fused_two = fused && can_two && (!can_one || c->fused_wgs == 2 || (c->fused_wgs == 0 && plan->fit_two >= 0.75));
   const size_t lds_fused = (size_t)(fused_two ? QKF_XCAP_TWO : QKF_XCAP_ONE) * 16 + lds_meta;
   const int grid = (int)std::min<long long>(units, (long long)(fused ? (fused_two ? 2 : 1) : c->wgs_per_cu) * c->num_cus);
   const size_t need = (size_t)grid * (size_t)chains * 2 * (size_t)(x_plane + t_plane) * sizeof(double);
@@ -835,7 +855,7 @@ extern "C" int qk_get_stats(qk_ctx* c, qk_stats* out) {
 static int plan_for_sets(const qk_mps_set* xs, const qk_mps_set* ys, qk_plan** plan) {
   const bool sym = (ys == nullptr || ys == xs);
   return qk_plan_create(xs->n_sites, xs->n_states, xs->dims_true.data(), sym ? xs->n_states : ys->n_states,
-                        sym ? nullptr : ys->dims_true.data(), sym ? QK_PLAN_SYMMETRIC : 0u, 1, 0, 0, plan);
+                        sym ? nullptr : ys->dims_true.data(), sym ? (QK_PLAN_SYMMETRIC | QK_PLAN_ORIENT) : 0u, 1, 0, 0, plan);
 }
 
 struct PlanGuard {  // a plan owned by one call

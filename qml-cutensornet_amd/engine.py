@@ -18,6 +18,7 @@ LIB_PATH = os.path.join(_HERE, "libqkgram.so")
 QK_LAYOUT_LPR, QK_LAYOUT_LRP = 0, 1
 QK_PLAN_SYMMETRIC = 1
 QK_PLAN_QUADS = 2  # 2x2 blocks of pairs per workgroup (include/qkgram.h)
+QK_PLAN_ORIENT = 4  # symmetric plans: list each pair in the cheaper order of contraction
 
 
 class QkError(RuntimeError):
@@ -174,7 +175,7 @@ def pack_state(mps, layout=QK_LAYOUT_LPR):
 class Plan:
     """Ordered share of the Gram's (x, y) pairs for one rank (host object)."""
 
-    def __init__(self, x_dims, y_dims=None, world_size=1, rank=0, block=0, quads=False):
+    def __init__(self, x_dims, y_dims=None, world_size=1, rank=0, block=0, quads=False, orient=None):
         L = lib()
         xd = np.ascontiguousarray(x_dims, dtype=np.int32)
         self.symmetric = y_dims is None
@@ -182,11 +183,14 @@ class Plan:
         self.nx = xd.shape[0]
         self.ny = self.nx if self.symmetric else yd.shape[0]
         n_sites = xd.shape[1] - 1
+        if orient is None:  # default: on (QK_PLAN_ORIENT=0 lists every pair of a symmetric plan as i <= j)
+            orient = os.environ.get("QK_PLAN_ORIENT", "1") != "0"
+        self.orient = bool(orient) and self.symmetric and not quads
         h = _P()
         _check(
             L.qk_plan_create(
                 n_sites, self.nx, xd.ctypes.data, self.ny, None if yd is None else yd.ctypes.data,
-                (QK_PLAN_SYMMETRIC if self.symmetric else 0) | (QK_PLAN_QUADS if quads else 0), world_size, rank, block, C.byref(h),
+                (QK_PLAN_SYMMETRIC if self.symmetric else 0) | (QK_PLAN_QUADS if quads else 0) | (QK_PLAN_ORIENT if self.orient else 0), world_size, rank, block, C.byref(h),
             ),
             "qk_plan_create",
         )

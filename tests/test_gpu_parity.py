@@ -520,3 +520,35 @@ def test_cfg5_real_states(gpu_ctx, monkeypatch):
     monkeypatch.setenv("QK_SMALL", "0")
     with engine.context(0) as ctx_ring:
         _check_real_workload(ctx_ring, states, 3)
+
+
+def test_both_contraction_orders_agree(gpu_ctx):
+    """X1: <x_i|x_j> contracted with x_j as the Y state (the order QK_PLAN_ORIENT may pick) and with x_i as the Y state give
+    conjugate overlaps to 1e-13 -- on ragged states where the two orders do different amounts of padded work."""
+    import qml_cutensornet_amd as Q
+    from qml_cutensornet_amd import engine
+
+    rng = np.random.default_rng(31)
+    n = 18
+
+    def skewed(cap, late):  # bonds that peak late (slow rise, fast fall) or early: the two orders then differ a lot in padded work
+        up = [min(cap, int(1.45**k) + (k > 0)) for k in range(n + 1)]
+        dn = [min(cap, 2 ** (n - k)) for k in range(n + 1)]
+        prof = [min(u, d, 2 ** min(k, n - k)) for k, (u, d) in enumerate(zip(up, dn))]
+        return prof if late else prof[::-1]
+
+    xs = [Q.random_mps(n, skewed(cap, late), rng) for cap, late in ((90, True), (120, False), (60, True), (130, True), (100, False), (70, False))]
+    with gpu_ctx.upload(xs) as dx:
+        plain, orient = engine.Plan(dx.dims, orient=False), engine.Plan(dx.dims, orient=True)
+        v0, z0 = gpu_ctx.gram_values_host(dx, None, plain, want_z=True)
+        v1, z1 = gpu_ctx.gram_values_host(dx, None, orient, want_z=True)
+        zmap = {(i, j): z for (i, j), z in zip(plain.pairs().tolist(), z0)}
+        turned = 0
+        for (i, j), v, z in zip(orient.pairs().tolist(), v1, z1):
+            ref = zmap[(i, j)] if (i, j) in zmap else np.conj(zmap[(j, i)])
+            turned += (i, j) not in zmap
+            assert abs(z - ref) < 1e-13 and abs(v - abs(ref) ** 2) < 1e-13
+        assert turned > 0
+        K = gpu_ctx.gram(dx)  # (plans of the convenience calls are oriented too)
+        assert np.array_equal(K, K.T) and np.abs(np.diag(K) - 1).max() < 1e-12
+        plain.close(), orient.close()

@@ -203,7 +203,7 @@ def test_plan_partitions_the_gram(built, world, symmetric):
     yd[:, 1:-1] = rng.integers(1, 90, size=(ny, n - 1))
     seen, costs, counts = set(), [], []
     for r in range(world):
-        p = engine.Plan(xd, None if symmetric else yd, world, r, block=8)
+        p = engine.Plan(xd, None if symmetric else yd, world, r, block=8, orient=False)
         pr = p.pairs()
         st = p.stats()
         assert st["pairs"] == len(pr) == p.num_pairs
@@ -222,6 +222,31 @@ def test_plan_partitions_the_gram(built, world, symmetric):
     assert max(counts) - min(counts) <= 1
     if world > 1:
         assert max(costs) / np.mean(costs) < 1.2  # the deal balances work, not only counts
+
+
+def test_oriented_plan_lists_each_pair_once_in_the_cheaper_order(built):
+    """QK_PLAN_ORIENT (X1: contraction order chosen on the host): every unordered pair exactly once, as (i, j) or (j, i),
+    and the listed order is the one the cost model prefers -- so the plan's padded work can only go down."""
+    from qml_cutensornet_amd import engine
+
+    rng = np.random.default_rng(5)
+    nx, n = 23, 10
+    xd = np.ones((nx, n + 1), dtype=np.int32)
+    xd[:, 1:-1] = rng.integers(1, 130, size=(nx, n - 1))
+    plain, orient = engine.Plan(xd, orient=False), engine.Plan(xd, orient=True)
+    pr = orient.pairs()
+    assert sorted(map(tuple, np.sort(pr, axis=1).tolist())) == sorted(map(tuple, plain.pairs().tolist()))
+    assert (pr[:, 0] > pr[:, 1]).any()  # some pairs were turned around
+    assert orient.stats()["flops"] == plain.stats()["flops"]  # the algorithmic count is symmetric in x and y
+    assert orient.stats()["padded_flops"] <= plain.stats()["padded_flops"]
+
+    def cost(a, b):  # the planner's model (qkgram.hip: fused_cost)
+        p16 = lambda v: -(-v // 16)
+        return sum(6 * p16(a[k]) * p16(b[k + 1]) * -(-b[k] // 4) + 6 * p16(b[k + 1]) * p16(a[k + 1]) * -(-a[k] // 4) for k in range(n))
+
+    for i, j in pr.tolist():
+        assert cost(xd[i], xd[j]) <= cost(xd[j], xd[i])
+    plain.close(), orient.close()
 
 
 @pytest.mark.parametrize("world", [1, 3])
