@@ -52,6 +52,15 @@ class TorchComm:
     def barrier(self):
         self._dist.barrier(group=self.group)
 
+    def allgather_array(self, arr: np.ndarray):
+        """All-gather of equally sized host arrays as tensors (no pickling): the packed set images on the host route."""
+        import torch
+
+        mine = torch.from_numpy(np.ascontiguousarray(arr))
+        parts = [torch.empty_like(mine) for _ in range(self.Get_size())]
+        self._dist.all_gather(parts, mine, group=self.group)
+        return [p.numpy() for p in parts]
+
     def backend(self) -> str:
         return self._dist.get_backend(self.group)
 
@@ -131,7 +140,12 @@ def exchange_sets(comm, ctx, local, lo: int, total: int, force_collective: bool 
         mine = np.zeros(mx, dtype=np.float64)
         if local is not None:
             local.copy_image(mine.ctypes.data, mx)
-        parts = comm_allgather(comm, mine) if size > 1 else [mine]
+        if size == 1:
+            parts = [mine]
+        elif hasattr(comm, "allgather_array") and comm.backend() != "nccl":
+            parts = comm.allgather_array(mine)
+        else:
+            parts = comm_allgather(comm, mine)
         joined = np.concatenate(parts)
         full = ctx.set_from_packed(dims_all, offs_all, joined.ctypes.data, joined.shape[0])
     return full, time.perf_counter() - t0
