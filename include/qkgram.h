@@ -78,8 +78,8 @@ typedef struct qk_stats {
 #define QK_KERNEL_NONE 0
 #define QK_KERNEL_WAVE 1    /* qk_sweep_wave_kernel: one pair per wavefront, bonds <= 16, fp64           */
 #define QK_KERNEL_SMALL 2   /* qk_sweep_small_kernel: X, T in LDS, bonds <= 32                            */
-#define QK_KERNEL_FUSED1 3  /* qk_sweep_fused_kernel<8, 4, 8192>: site-fused sweep, one workgroup per CU  */
-#define QK_KERNEL_FUSED2 4  /* qk_sweep_fused_kernel<4, 4, 4608>: site-fused sweep, two workgroups per CU */
+#define QK_KERNEL_FUSED1 3  /* qk_sweep_fused_kernel<12, 2, 8192, 3>: site-fused sweep, one workgroup per CU */
+#define QK_KERNEL_FUSED2 4  /* qk_sweep_fused_kernel<8, 1, 4608, 4>: site-fused sweep, two workgroups per CU */
 #define QK_KERNEL_RING 5    /* qk_sweep_ring_kernel: X, T in an L2-resident scratch                       */
 #define QK_KERNEL_LAB 6     /* an experimental kernel (libqklab.so only)                                  */
 /* the kernel's name as rocprofv3 prints it (without the "void " and the argument list) */

@@ -26,9 +26,12 @@
 //     loaded like the site tensors), X' is accumulated a block of b' rows at a time (as many as fit the LDS), items in
 //     rounds of (waves x slots), and written to the other global buffer;
 //   * per-site control is a 48-byte record per site, computed by all threads at pair set-up.
-// Two launch shapes (chosen per launch from the plan, qkgram.hip): one 8-wave workgroup per CU with an 8192-element X
-// buffer, or two 4-wave workgroups with 4608 elements each -- the second workgroup fills the first one's barriers and
-// per-site set-up, which pays while most of the work sits in sites that fit the smaller buffer.
+// Two launch shapes (chosen per launch from the plan, qkgram.hip): one 12-wave workgroup per CU (three waves per SIMD at
+// 168 VGPRs, two T slots per wave) with an 8192-element X buffer, or two 8-wave workgroups (128 VGPRs, one slot) with
+// 4608 elements each -- the second workgroup fills the first one's barriers and per-site set-up, which pays while most
+// of the work sits in sites that fit the smaller buffer.  A wave issues in order, so its tails, set-up and load waits
+// stall its own matrix stream: the more waves share a SIMD, the better the matrix pipe is fed (8 waves x 4 slots: 482 ms
+// on the headline set, 12 x 2: 452 ms, 16 x 1: 455 ms with a few spilled registers).
 // fp64 only: the f32 MFMA's C layout (C[4q + r][j]) is not an operand layout (the complex64 sweep stays on qk_ring.h).
 #pragma once
 #include "qk_device.h"
@@ -42,10 +45,9 @@ typedef double v2d __attribute__((ext_vector_type(2)));
 typedef __attribute__((address_space(3))) v2d lds_v2d;
 
 // Two shapes are shipped (qkgram.hip picks one per launch from the plan's work profile):
-//   <8 waves, 4 slots, 8192-element X buffer>: one workgroup per CU  -- large bonds (more sites stay LDS-resident)
-//   <4 waves, 4 slots, 4608-element X buffer>: two workgroups per CU -- small / medium bonds (the second workgroup
+//   <12 waves, 2 slots, 8192-element X buffer, 3 waves per SIMD>: one workgroup per CU -- large bonds (more sites stay LDS-resident)
+//   <8 waves, 1 slot, 4608-element X buffer, 4 waves per SIMD>: two workgroups per CU -- small / medium bonds (the second workgroup
 //                                              fills the first one's barriers and per-site set-up)
-static constexpr int QKF_SLOTS = 4;  // T slots (items) per wave and round: 16 VGPRs each
 
 // one complex k-step, 3M form: (ar + i ai) * (br + i s bi), s = +1 | -1 (CONJB)
 template <bool CONJB>
@@ -155,20 +157,28 @@ __device__ __forceinline__ void qkf_p2_item(const QkfTile& t, v2d (&fr)[4], cons
 // The T tiles of a wave live in registers, S slots.  The slot loops are NOT unrolled (unrolled, every slot drags ~50
 // VGPRs of hoisted address state through the whole sweep) and the working slot is always T[S-1]: when a round gives
 // the waves up to L > 1 items each, the last L slots are turned by one before each item (phase 1 makes all L turns, so
-// that item s ends in slot S-L+s; phase 2 turns once per item, which brings item s to slot S-1).  S = 4 is assumed.
+// that item s ends in slot S-L+s; phase 2 turns once per item, which brings item s to slot S-1).  S <= 4.
 template <int S>
-__device__ __forceinline__ void qkf_rotate(QkfTile (&T)[S], const int L) {  // turn the last L slots by one: T[S-L] goes to T[S-1]
-  if (L == 2) {
-    const QkfTile t = T[S - 2];
-    T[S - 2] = T[S - 1], T[S - 1] = t;
-  } else if (L == 3) {
-    const QkfTile t = T[S - 3];
-    T[S - 3] = T[S - 2], T[S - 2] = T[S - 1], T[S - 1] = t;
-  } else if (L >= 4) {
-    const QkfTile t0 = T[0];
+__device__ __forceinline__ void qkf_rotate(QkfTile (&T)[S], const int L) {  // turn the last L <= S slots by one: T[S-L] goes to T[S-1]
+  if constexpr (S >= 2) {
+    if (L == 2) {
+      const QkfTile t = T[S - 2];
+      T[S - 2] = T[S - 1], T[S - 1] = t;
+    }
+  }
+  if constexpr (S >= 3) {
+    if (L == 3) {
+      const QkfTile t = T[S - 3];
+      T[S - 3] = T[S - 2], T[S - 2] = T[S - 1], T[S - 1] = t;
+    }
+  }
+  if constexpr (S >= 4) {
+    if (L >= 4) {
+      const QkfTile t0 = T[0];
 #pragma unroll
-    for (int e = 0; e + 1 < S; ++e) T[e] = T[e + 1];
-    T[S - 1] = t0;
+      for (int e = 0; e + 1 < S; ++e) T[e] = T[e + 1];
+      T[S - 1] = t0;
+    }
   }
 }
 
@@ -181,8 +191,8 @@ struct QkfSite {
 typedef int v4i __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) v4i lds_v4i;
 
-template <int NW, int S, int XCAP>  // waves per workgroup; T slots per wave (a round holds NW * S items); elements of the LDS X buffer
-__global__ __launch_bounds__(64 * NW, 2) void qk_sweep_fused_kernel(const SweepArgs g) {
+template <int NW, int S, int XCAP, int WPS>  // waves per workgroup; T slots per wave (a round holds NW * S items); elements of the LDS X buffer; waves per SIMD (register budget)
+__global__ __launch_bounds__(64 * NW, WPS) void qk_sweep_fused_kernel(const SweepArgs g) {
   constexpr int NT = 64 * NW;
   extern __shared__ __attribute__((aligned(16))) double lds_raw[];
   lds_v2d* const XL = (lds_v2d*)lds_raw;  // (a C-style cast: the generic -> LDS address-space cast)

@@ -106,6 +106,19 @@ extern "C" int qk_pack_state(int32_t n_sites, const int32_t* bond_dims, const do
 // Algorithmic flops of one overlap: 8 real flops per complex
 // multiply-add, cheaper association per site.  Padded: what this engine executes.
 static constexpr int QKF_XCAP_ONE = 8192, QKF_XCAP_TWO = 4608;  // elements of the fused sweep's LDS X buffer with one / two workgroups per CU
+// shapes of the two instantiations: waves per workgroup, T slots per wave, waves per SIMD (experiment builds override them)
+#ifndef QKF_ONE_NW
+#define QKF_ONE_NW 12  // three waves per SIMD at 168 VGPRs: 452 against 482 ms for 8 waves x 4 slots on the headline set (16 x 1: 455)
+#define QKF_ONE_S 2
+#define QKF_ONE_WPS 3
+#endif
+#ifndef QKF_TWO_NW
+#define QKF_TWO_NW 8  // four waves per SIMD at 128 VGPRs, one slot: 16.4 against 18.2 ms for 4 waves x 4 slots on the 40-qubit x 4-layer set
+#define QKF_TWO_S 1
+#define QKF_TWO_WPS 4
+#endif
+#define QKF_KERNEL_ONE qk_sweep_fused_kernel<QKF_ONE_NW, QKF_ONE_S, QKF_XCAP_ONE, QKF_ONE_WPS>
+#define QKF_KERNEL_TWO qk_sweep_fused_kernel<QKF_TWO_NW, QKF_TWO_S, QKF_XCAP_TWO, QKF_TWO_WPS>
 static void pair_work(int n, const int32_t* a, const int32_t* b, double* flops, double* padded, double* bytes, double* fit_two = nullptr) {
   double f = 0, fp = 0, by = 0, ft = 0;
   for (int k = 0; k < n; ++k) {
@@ -401,8 +414,8 @@ static int ctx_init(qk_ctx* c, int device_id, int num_cus) {
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(qk_sweep_ring_kernel<double>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(qk_sweep_small_kernel<double>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(qk_sweep_small_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
-  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(qk_sweep_fused_kernel<8, QKF_SLOTS, QKF_XCAP_ONE>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(qk_sweep_fused_kernel<4, QKF_SLOTS, QKF_XCAP_TWO>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(QKF_KERNEL_ONE), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(QKF_KERNEL_TWO), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
 #ifdef QK_LAB  // libqklab.so only: the experimental kernels of qk_lab.hip, selectable with QK_VARIANT
   {
     const int rc = qk_lab_init(c);
@@ -699,8 +712,8 @@ extern "C" int qk_gram_values(qk_ctx* c, const qk_mps_set* xs, const qk_mps_set*
   const long long t_plane = 2 * x_plane;
   const long long units = quad ? np / 4 : grouped ? (long long)plan->groups.size() / 2 : (duo ? (np + 1) / 2 : np);
   const int max_pad = std::max(xs->max_pad, ys->max_pad);
-  // the site-fused sweep (qk_fused.h), fp64.  Two shapes: one 8-wave workgroup per CU with an 8192-element X buffer, or two
-  // 4-wave workgroups with 4608 elements each.  The second workgroup fills the first one's barriers and per-site set-up
+  // the site-fused sweep (qk_fused.h), fp64.  Two shapes: one 12-wave workgroup per CU (three waves per SIMD, two T slots
+  // each) with an 8192-element X buffer, or two 8-wave workgroups (four waves per SIMD, one slot) with 4608 elements each.  The second workgroup fills the first one's barriers and per-site set-up
   // (+24 % on the 40-qubit x 4-layer set), but every site that does not fit the smaller buffer runs in strips from a global
   // X: on the 60-qubit x 6-layer headline set (57 % of the work fits) the two shapes are within 2 % in time while the
   // smaller buffer moves 3.2 instead of 1.9 TB through the fabric -- so two workgroups only when >= 75 % of the padded
@@ -772,8 +785,8 @@ extern "C" int qk_gram_values(qk_ctx* c, const qk_mps_set* xs, const qk_mps_set*
     a.xdata = xs->d_il, a.ydata = ys->d_il;
     a.x_plane = (long long)xs->max_pad * ys->max_pad;  // complex elements per global X buffer (two per workgroup)
     HIP_TRY(hipEventRecord(c->ev0, c->stream));        // the conversion above is not part of the sweep
-    if (fused_two) qk_sweep_fused_kernel<4, QKF_SLOTS, QKF_XCAP_TWO><<<dim3(grid), dim3(256), lds_fused, c->stream>>>(a);
-    else qk_sweep_fused_kernel<8, QKF_SLOTS, QKF_XCAP_ONE><<<dim3(grid), dim3(512), lds_fused, c->stream>>>(a);
+    if (fused_two) QKF_KERNEL_TWO<<<dim3(grid), dim3(64 * QKF_TWO_NW), lds_fused, c->stream>>>(a);
+    else QKF_KERNEL_ONE<<<dim3(grid), dim3(64 * QKF_ONE_NW), lds_fused, c->stream>>>(a);
     c->last.kernel = fused_two ? QK_KERNEL_FUSED2 : QK_KERNEL_FUSED1;
   } else if (f32) {  // complex64 sweep: the ring kernel on fp32 planes; QK_VARIANT does not apply
     qk_sweep_ring_kernel<float><<<dim3(grid), dim3(512), lds_ring, c->stream>>>(a);
@@ -828,14 +841,17 @@ extern "C" const char* qk_kernel_name(int32_t kernel, int32_t precision) {
   switch (kernel) {
     case QK_KERNEL_WAVE: return "qk_sweep_wave_kernel<0>";
     case QK_KERNEL_SMALL: return f32 ? "qk_sweep_small_kernel<float>" : "qk_sweep_small_kernel<double>";
-    case QK_KERNEL_FUSED1: return "qk_sweep_fused_kernel<8, 4, 8192>";
-    case QK_KERNEL_FUSED2: return "qk_sweep_fused_kernel<4, 4, 4608>";
+    case QK_KERNEL_FUSED1: return "qk_sweep_fused_kernel<12, 2, 8192, 3>";
+    case QK_KERNEL_FUSED2: return "qk_sweep_fused_kernel<8, 1, 4608, 4>";
     case QK_KERNEL_RING: return f32 ? "qk_sweep_ring_kernel<float>" : "qk_sweep_ring_kernel<double>";
     case QK_KERNEL_LAB: return "(lab kernel)";
     default: return "(none)";
   }
 }
-static_assert(QKF_SLOTS == 4 && QKF_XCAP_ONE == 8192 && QKF_XCAP_TWO == 4608, "qk_kernel_name spells the fused sweep's template arguments");
+#ifndef QKF_EXPERIMENT
+static_assert(QKF_ONE_NW == 12 && QKF_ONE_S == 2 && QKF_ONE_WPS == 3 && QKF_TWO_NW == 8 && QKF_TWO_S == 1 && QKF_TWO_WPS == 4 && QKF_XCAP_ONE == 8192 && QKF_XCAP_TWO == 4608,
+              "qk_kernel_name spells the fused sweep's template arguments");
+#endif
 
 extern "C" int qk_get_stats(qk_ctx* c, qk_stats* out) {
   if (!c || !out) return fail(QK_EINVAL, "qk_get_stats: null argument");
