@@ -46,6 +46,88 @@ def _say(is_root, text):
         sys.stdout.flush()
 
 
+_PILOT_MIN_STATES = 24  # below this a share goes to the device builder as a whole (states that outgrow the cap: host)
+
+
+def _entangling_weight(circuit):
+    """Cost proxy of a circuit: sum of sin^2(pi alpha) over its XXPhase gates (alpha in half-turns: 0 and 1 do not
+    entangle).  The device builder orders its queue by the same quantity; it tracks the bonds a state will reach."""
+    xx = np.asarray(circuit.op) == 2
+    return float((np.sin(np.pi * np.asarray(circuit.alpha)[xx]) ** 2).sum())
+
+
+def _hybrid_build(ctx, circuits, fidelity, cap, host_workers, is_root, label):
+    """QK_BUILDER=hybrid for a large share: the device builder (bonds capped at ``cap``) and the host pool work AT THE SAME
+    TIME, and a state predicted to outgrow the cap never visits the device.
+      1. the heaviest quarter (by the cost proxy) starts on the host pool at once -- whatever the prediction will say,
+         these are the states the host is the better tool for;
+      2. meanwhile a pilot of 8 states spread over the rest runs on the device (partial): the lightest state it drops
+         sets the threshold of the prediction;
+      3. predicted-to-fit states go to the device in one launch while the host pool takes the others;
+      4. what the device still drops (misprediction) is built on the host at the end.
+    Returns (list[MPS], seconds per state), or None when the device builder fails (the caller falls back)."""
+    import threading
+
+    m = len(circuits)
+    w = np.array([_entangling_weight(c) for c in circuits])
+    order = np.argsort(w)  # lightest first
+    states, secs = [None] * m, [0.0] * m
+
+    def host(idx, box):
+        t0 = time.perf_counter()
+        built, bsecs = simulate_many([circuits[k] for k in idx], fidelity, workers=host_workers)
+        for k, mps, dt in zip(idx, built, bsecs):
+            states[k], secs[k] = mps, dt
+        box.append(time.perf_counter() - t0)
+
+    def device(idx):
+        t0 = time.perf_counter()
+        built, info = ctx.build_mps([circuits[k] for k in idx], fidelity, max_bond=cap, partial=True)
+        dt = (time.perf_counter() - t0) / max(1, len(idx))
+        dropped = []
+        for pos, k in enumerate(idx):
+            if built[pos] is None:
+                dropped.append(k)
+            else:
+                states[k], secs[k] = built[pos], dt
+        return dropped
+
+    heavy = [int(k) for k in order[m - m // 4 :]]
+    rest = [int(k) for k in order[: m - m // 4]]
+    pilot = sorted({rest[int(round(f * (len(rest) - 1)))] for f in np.linspace(0.0, 1.0, 8)})
+    box_a = []
+    th = threading.Thread(target=host, args=(heavy, box_a))
+    th.start()
+    try:
+        pilot_dropped = device(pilot)
+    except _engine.QkError as exc:
+        th.join()
+        _say(is_root, f"{label}: device builder gave up on the pilot ({exc}); building on the host")
+        return None
+    thr = min((w[k] for k in pilot_dropped), default=np.inf)  # lightest state the device could not hold
+    others = [k for k in rest if k not in pilot]
+    dev_idx = [k for k in others if w[k] < thr]
+    host_idx = [k for k in others if w[k] >= thr] + pilot_dropped
+    _say(is_root, f"{label}: pilot of {len(pilot)}: {len(pilot_dropped)} outgrew bond {cap}; device builder takes {len(dev_idx)} states, host pool {len(heavy) + len(host_idx)}")
+    th.join()
+    box_b = []
+    th = threading.Thread(target=host, args=(host_idx, box_b)) if host_idx else None
+    if th:
+        th.start()
+    late = []
+    try:
+        if dev_idx:
+            late = device(dev_idx)
+    except _engine.QkError as exc:
+        _say(is_root, f"{label}: device builder gave up ({exc}); its states go to the host")
+        late = dev_idx
+    if th:
+        th.join()
+    if late:
+        host(late, [])
+    return states, secs
+
+
 def _simulate_share(ansatz, points, rank, n_procs, fidelity, is_root, label, device_id=0, host_workers=1, want_set=True):
     """This rank's slice of the data set (contiguous chunks of ceil(N/P), as ref :154,:171-174) -> (first index, the
     states as ONE packed device set -- ``None`` for an empty share --, seconds per state, fidelities).  ``want_set=False``
@@ -55,18 +137,34 @@ def _simulate_share(ansatz, points, rank, n_procs, fidelity, is_root, label, dev
     per_rank = -(-len(points) // n_procs)
     lo = min(len(points), rank * per_rank)
     hi = min(len(points), lo + per_rank)
-    which = os.environ.get("QK_BUILDER", "auto") if want_set else "host"  # auto | device | host
-    if which in ("device", "auto") and hi > lo:
+    which = os.environ.get("QK_BUILDER", "auto") if want_set else "host"  # auto | device | hybrid | host
+    if which == "auto":
+        # "never lose": the device builder takes the share only where it is known to win -- every bond is bounded by
+        # 2^(distance x layers) <= 64 (no state can outgrow the cap: one launch, nothing downloaded) and the share is large
+        # enough to fill the GPU (a state occupies one workgroup).  Elsewhere the host pool is at least as fast
+        # (profiles/r02/builder_policy.txt); QK_BUILDER=hybrid runs both at once behind a pilot, QK_BUILDER=device forces it.
+        dist_max = max((abs(int(b_) - int(a_)) for a_, b_ in getattr(ansatz, "entanglement_map", [])), default=0)
+        bound = 2 ** min(dist_max * int(getattr(ansatz, "reps", 0)), int(ansatz.num_qubits) // 2)
+        which = "device" if (bound <= 64 and hi - lo >= 32) else "host"
+    if which in ("device", "hybrid") and hi > lo:
         # the rank's whole share in ONE launch of the device builder (csrc/qk_build.hip): what the reference does with
         # simulate(libhandle, ...) on the rank's GPU (ref :221,:263).  Pays off at the small bonds of the reference's own
-        # runs (profiles/r01/device_builder_bench.txt).  "auto" (the default) runs the device builder with bonds capped at 64
-        # -- the regime where it wins -- and builds only the states that outgrow the cap with the host builder, as this
-        # loop always did; "host" skips the device builder, "device" uses it alone (max_bond 256) and fails on overflow.
+        # runs (profiles/r01/device_builder_bench.txt).  "device" uses it alone (max_bond 256) and fails on overflow;
+        # "hybrid" caps its bonds at 64 and builds what outgrows the cap on the host pool -- concurrently, behind a pilot,
+        # for shares of >= 24 states (_hybrid_build); "host" skips it.
         t0 = time.perf_counter()
         cap = int(os.environ.get("QK_BUILDER_MAX_BOND", "256" if which == "device" else "64"))
+        partial = which == "hybrid"
         circuits = [ansatz.circuit_for_data(points[k, :]) for k in range(lo, hi)]
+        ctx = _engine.default_context(device_id)
+        if which == "hybrid" and hi - lo >= _PILOT_MIN_STATES:
+            out = _hybrid_build(ctx, circuits, fidelity, cap, host_workers, is_root, label)
+            if out is not None:
+                states, secs = out
+                _say(is_root, f"{label}: 100%")
+                return lo, ctx.upload(states), secs, [m.fidelity for m in states]
         try:
-            dset, states, binfo = _engine.default_context(device_id).build_share(circuits, fidelity, max_bond=cap, partial=(which == "auto"))
+            dset, states, binfo = ctx.build_share(circuits, fidelity, max_bond=cap, partial=partial)
         except _engine.QkError as exc:
             if which == "device":
                 raise
@@ -84,7 +182,7 @@ def _simulate_share(ansatz, points, rank, n_procs, fidelity, is_root, label, dev
                 for k, m, dt_k in zip(binfo["dropped"], built, bsecs):
                     states[k], secs[k] = m, dt_k
             _say(is_root, f"{label}: 100%")
-            return lo, _engine.default_context(device_id).upload(states), secs, [m.fidelity for m in states]
+            return lo, ctx.upload(states), secs, [m.fidelity for m in states]
     # host builder: one circuit per core on a thread pool (no fork: the GPU may already be initialised; the native builder
     # releases the GIL) -- the reference's loop is serial because its simulate() runs on the GPU (ref :213-231)
     tick, done = max(1, per_rank // 10), [0]

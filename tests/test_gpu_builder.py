@@ -141,8 +141,8 @@ def test_built_states_stay_on_the_device(gpu_ctx):
     dset.close()
 
 
-def test_auto_builder_falls_back_to_the_host(built, monkeypatch, capsys):
-    """QK_BUILDER=auto: the device builder with bonds capped (here at 4, so that it must give up), then the host builder."""
+def test_hybrid_builder_falls_back_to_the_host(built, monkeypatch, capsys):
+    """QK_BUILDER=hybrid: the device builder with bonds capped (here at 4, so that it must give up), then the host builder."""
     import qml_cutensornet_amd as Q
     from qml_cutensornet_amd.dist import SingleComm
     from qml_cutensornet_amd.gpu_backend.kernel_state_ansatz import KernelStateAnsatz, build_kernel_matrix
@@ -150,7 +150,7 @@ def test_auto_builder_falls_back_to_the_host(built, monkeypatch, capsys):
     g = golden("deep_10q_r3_d3.npz")
     n, reps, gamma = int(g["n"]), int(g["reps"]), float(g["gamma"])
     ans = KernelStateAnsatz(num_qubits=n, reps=reps, gamma=gamma, entanglement_map=Q.entanglement_graph(n, int(g["d"])), hadamard_init=True)
-    monkeypatch.setenv("QK_BUILDER", "auto")
+    monkeypatch.setenv("QK_BUILDER", "hybrid")
     monkeypatch.setenv("QK_BUILDER_MAX_BOND", "4")
     K = build_kernel_matrix(SingleComm(), ans, X=g["X_train"], truncation_error=1e-16)
     assert "on the host" in capsys.readouterr().out
@@ -196,3 +196,52 @@ def test_build_kernel_matrix_with_host_builder_pool(built, monkeypatch):
     ans = KernelStateAnsatz(num_qubits=n, reps=reps, gamma=gamma, entanglement_map=Q.entanglement_graph(n, int(g["d"])), hadamard_init=True)
     K = build_kernel_matrix(SingleComm(), ans, X=g["X_train"], truncation_error=1e-16)
     assert np.abs(K - g["K_train"]).max() < 1e-10
+
+
+def test_hybrid_builder_policy(gpu_ctx, monkeypatch, capsys):
+    """QK_BUILDER=hybrid on a share large enough for the pilot (>= 24 states): the heaviest quarter starts on the host pool, a
+    pilot of 8 runs on the device at the same time and sets the prediction threshold, predicted-to-fit states are built
+    on the device while the host pool takes the rest.  With a cap of 8 on a 14-qubit, 3-layer, d=2 ansatz some states fit
+    and some do not.  Every state must equal the host builder's (|<a|b>|^2 = 1), whoever built it."""
+    import qml_cutensornet_amd as Q
+    from oracle import restatement as R
+    from qml_cutensornet_amd.gpu_backend import kernel_state_ansatz as M
+
+    n, reps, d = 14, 3, 2
+    X = R.synthetic_features(32, n, 9)
+    X[:6] = 1.0 + 0.02 * (X[:6] - 1.0)  # six nearly product states (tiny XXPhase angles): light ones that fit any cap
+    ans = Q.KernelStateAnsatz(n, reps, 1.0, Q.entanglement_graph(n, d))
+    circuits = [ans.circuit_for_data(x) for x in X]
+    weights = [M._entangling_weight(c) for c in circuits]
+    assert max(weights[:6]) < min(weights[6:])
+    states, secs = M._hybrid_build(gpu_ctx, circuits, 1 - 1e-16, 8, 4, True, "X")
+    out = capsys.readouterr().out
+    assert "pilot of" in out and "device builder takes" in out
+    assert len(states) == 32 and all(m is not None for m in states) and all(t >= 0 for t in secs)
+    ref = [Q.simulate(c, 1 - 1e-16) for c in circuits]
+    for a, b in zip(states, ref):
+        assert abs(abs(R.mps_inner(a.tensors, b.tensors)) ** 2 - 1) < 1e-9
+    assert max(m.max_bond() for m in states) > 8  # (so the cap did bite: those states came from the host pool)
+
+
+def test_auto_builder_uses_the_device_only_where_it_cannot_lose(built, monkeypatch, capsys):
+    """QK_BUILDER=auto (the default): device builder iff every bond is bounded by 2^(distance x layers) <= 64 and the share has
+    >= 32 states (one launch, the share stays on the device); host pool otherwise.  Same Gram either way."""
+    import qml_cutensornet_amd as Q
+    from oracle import restatement as R
+    from qml_cutensornet_amd.dist import SingleComm
+    from qml_cutensornet_amd.gpu_backend import kernel_state_ansatz as M
+
+    monkeypatch.setenv("QK_BUILDER", "auto")
+    n = 16  # (bonds are also bounded by 2^(n/2) = 256 here, above the cap)
+    X = R.synthetic_features(40, n, 3)
+    calls = []
+    real = M._engine.Context.build_share
+    monkeypatch.setattr(M._engine.Context, "build_share", lambda self, *a, **k: (calls.append(len(a[0])), real(self, *a, **k))[1])
+    for reps, d, expect_device in ((2, 2, True), (4, 2, False)):
+        calls.clear()
+        ans = Q.KernelStateAnsatz(n, reps, 1.0, Q.entanglement_graph(n, d))
+        K = M.build_kernel_matrix(SingleComm(), ans, X=X, truncation_error=1e-16)
+        assert (calls == [40]) == expect_device
+        K_ref = R.gram_from_mps([Q.simulate(ans.circuit_for_data(x), 1 - 1e-16).tensors for x in X[:6]])
+        assert np.abs(K[:6, :6] - K_ref).max() < 1e-9
