@@ -6,13 +6,17 @@
 // fewest singular values whose weight keeps the fidelity -- restated for the device:
 //   * all data points share ONE gate structure and differ only in the angles, so the whole list is one persistent
 //     launch: a workgroup pulls a state index from a device counter and runs that state's complete gate program;
-//   * the only dense factorisation is a one-sided (Hestenes) Jacobi sweep over column pairs, 16 lanes per pair and
-//     32 pairs per step in round-robin order: it serves as the SVD of a gate's theta matrix and, with the same code, as
-//     the rank-revealing orthogonalisation of a centre move (M = (W/s)(s V^H) instead of QR);
+//   * the only dense factorisation is a one-sided (Hestenes) Jacobi sweep over column pairs, GL = 8 lanes per pair and
+//     BT / GL = 32 pairs per step in round-robin order (256-thread workgroups): it serves as the SVD of a gate's theta
+//     matrix and, with the same code, as the rank-revealing orthogonalisation of a centre move (M = (W/s)(s V^H)
+//     instead of QR).  When A and V fit they are factorised in LDS (odd leading dimension: conflict-free for the 16-byte
+//     elements), otherwise from the L2-resident workspace;
 //   * site tensors live in a per-workgroup arena (fixed slots of 2*cap^2 complex), theta / V / temporaries in a
 //     per-workgroup workspace -- L2-resident at the bonds of the reference's workloads; finished states are packed
 //     into one heap (atomic bump) and described by dims / offsets / fidelity arrays.
-// Round-1 scope: correctness and a first measurement; the matrices stay in global memory (no LDS-resident path yet).
+// Where it stands: wins over the 16-core host pool at bonds <= 33 with hundreds of states, loses
+// beyond bond ~64 (a block Jacobi on the matrix cores is the missing piece); build_kernel_matrix uses it only where no
+// state can outgrow its bond cap (QK_BUILDER=auto).
 #include "qk_host.h"
 
 #include <algorithm>
