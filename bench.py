@@ -327,7 +327,7 @@ def main():
                 "traffic_tb_per_s": (traffic / (kms * 1e-3) / 1e12) if (traffic and kms > 0) else None,
                 "kernel_ms": kms,
                 "algorithmic_tflop_per_launch": my["flops"] / 1e12,
-                # the same count with every bond rounded up to the 16-wide MFMA tile (four-product form); the shipped kernel
+                # the same count with every bond rounded up to the 16-wide MFMA tile (four-product form); the sweep kernels
                 # issues 3/4 of the K-trimmed part of it (3M complex product): see profiles/r02/pmc_summary.json
                 "padded_4m_tflop_per_launch": my["padded_flops"] / 1e12,
                 "algorithmic_gbytes_per_launch": my["bytes"] / 1e9 * (1.0 if args.precision == "f64" else 0.5),

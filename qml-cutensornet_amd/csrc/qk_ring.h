@@ -1,5 +1,7 @@
 // qk_ring.h -- the ring GEMM (LDS-DMA staging ring + 3M complex product) and the sweep kernel built on it:
-// the shipped hot path (qk_sweep_ring_kernel<double>) and its complex64 form (qk_sweep_ring_kernel<float>).
+// round 1's hot path (qk_sweep_ring_kernel<double>; since round 2 the fp64 path of bonds > 512 and of QK_FUSED=0 -- the
+// site-fused sweep of qk_fused.h took over) and its complex64 form (qk_sweep_ring_kernel<float>); the small-bond and the
+// one-wave sweeps.
 #pragma once
 #include "qk_device.h"
 
@@ -300,7 +302,7 @@ __device__ __forceinline__ void zgemm_ring3(T* __restrict__ Cre, T* __restrict__
 // The sweep kernel: ONE persistent launch per Gram share.  Grid = 2 workgroups per CU, 8 waves each.  A workgroup
 // pulls pair indices from a device counter and carries the whole sweep of that pair; X and T live in a private
 // global scratch (L2 / Infinity Cache resident), the result |<x|y>|^2 (and z) is written as doubles.
-//   T = double: the shipped hot path (K-tile 8);
+//   T = double: K-tile 8 (round 1's headline kernel; now the fallback of the site-fused sweep);
 //   T = float : complex64 sweep on v_mfma_f32_16x16x4_f32 (K-tile 16: the same 16-KiB slots, pieces
 //               and roles).  The set is read as float planes with the SAME element offsets as the fp64 image
 //               (qk_mps_set_to_f32 converts element by element); the X/T scratch holds floats.

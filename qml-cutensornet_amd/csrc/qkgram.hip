@@ -791,7 +791,7 @@ extern "C" int qk_gram_values(qk_ctx* c, const qk_mps_set* xs, const qk_mps_set*
   } else if (f32) {  // complex64 sweep: the ring kernel on fp32 planes; QK_VARIANT does not apply
     qk_sweep_ring_kernel<float><<<dim3(grid), dim3(512), lds_ring, c->stream>>>(a);
     c->last.kernel = QK_KERNEL_RING;
-  } else if (c->variant == 20) {  // the shipped kernel: LDS-DMA staging ring (K-tile 8, three slots) + 3M complex product
+  } else if (c->variant == 20) {  // the ring sweep: LDS-DMA staging ring (K-tile 8, three slots) + 3M complex product
     qk_sweep_ring_kernel<double><<<dim3(grid), dim3(512), lds_ring, c->stream>>>(a);
     c->last.kernel = QK_KERNEL_RING;
   } else {  // experimental / diagnostic kernels (qk_lab.hip, libqklab.so only)

@@ -391,10 +391,10 @@ def test_small_bond_kernel(gpu_ctx, n, chi_max, nx, ny, seed, monkeypatch):
     assert np.abs(z - z_ring).max() < 1e-13
 
 
-# ------------------------------------------------------------------ randomised sweep over shapes (all three product kernels)
+# ------------------------------------------------------------------ randomised sweep over shapes (wave, small-bond and site-fused kernels)
 def test_randomised_shapes_against_oracle(gpu_ctx):
     """40 seeded random (sites, bond cap, set sizes): bond caps 2...70 exercise the register (<= 16), LDS-resident (<= 32)
-    and ring kernels, ragged profiles exercise the K-trim and the partially filled passes."""
+    and site-fused kernels, ragged profiles exercise the K-trim, ragged tile counts and the ping-pong / in-place X buffers."""
     import qml_cutensornet_amd as Q
     from oracle import restatement as R
 
@@ -552,3 +552,23 @@ def test_both_contraction_orders_agree(gpu_ctx):
         K = gpu_ctx.gram(dx)  # (plans of the convenience calls are oriented too)
         assert np.array_equal(K, K.T) and np.abs(np.diag(K) - 1).max() < 1e-12
         plain.close(), orient.close()
+
+
+def test_bonds_beyond_the_fused_sweep_take_the_ring_sweep(gpu_ctx):
+    """Bonds > 512 (one 16-row strip of X' no longer fits the fused sweep's LDS buffer): the engine falls back to the ring
+    sweep on its own, and says so in the stats."""
+    import qml_cutensornet_amd as Q
+    from oracle import restatement as R
+
+    rng = np.random.default_rng(23)
+    n = 22
+    xs = [Q.random_mps(n, [min(2 ** min(k, n - k), c) for k in range(n + 1)], rng) for c in (530, 90)]
+    z_ref = np.array([[R.mps_inner(x.tensors, y.tensors) for x in xs] for y in xs])
+    with gpu_ctx.upload(xs) as dx:
+        assert dx.info()["max_padded_bond"] == 544
+        z = gpu_ctx.overlaps(dx)
+        assert "ring" in gpu_ctx.stats()["kernel_name"]
+    assert np.abs(z - z_ref).max() < TOL
+    with gpu_ctx.upload(xs[1:]) as dy:  # the same state alone: the fused sweep
+        gpu_ctx.overlaps(dy)
+        assert "fused" in gpu_ctx.stats()["kernel_name"]
