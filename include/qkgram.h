@@ -82,6 +82,7 @@ typedef struct qk_stats {
 #define QK_KERNEL_FUSED2 4  /* qk_sweep_fused_kernel<8, 1, 4608, 4>: site-fused sweep, two workgroups per CU */
 #define QK_KERNEL_RING 5    /* qk_sweep_ring_kernel: X, T in an L2-resident scratch                       */
 #define QK_KERNEL_LAB 6     /* an experimental kernel (libqklab.so only)                                  */
+#define QK_KERNEL_WAVE2 7   /* qk_sweep_wave2_kernel: one pair per wavefront, bonds <= 32 (2 x 2 tiles), fp64 */
 /* the kernel's name as rocprofv3 prints it (without the "void " and the argument list) */
 const char* qk_kernel_name(int32_t kernel, int32_t precision);
 
@@ -174,10 +175,11 @@ int qk_plan_stats(const qk_plan* plan, qk_stats* out); /* algorithmic flops/byte
  * One persistent launch; returns after enqueueing (asynchronous).
  * yset = NULL means Y is X.
  * The sweep kernel is chosen from the two sets' largest padded bond and precision: 16 (fp64) -> one pair per
- * wavefront, entirely in registers; <= 32 -> X and T resident in LDS, site tensors streamed; larger fp64 bonds -> the
+ * wavefront, entirely in registers; <= 32 -> fp64: one pair per wavefront with 2 x 2 register tiles, complex64: X and T
+ * resident in LDS, site tensors streamed; larger fp64 bonds -> the
  * site-fused sweep (X in LDS, T in registers, qk_fused.h); complex64 sets and bonds > 512 -> the ring sweep (X / T in
  * an L2-resident scratch).  All compute the same chain of complex GEMMs on the matrix cores and agree to rounding
- * (tests/test_gpu_parity.py); QK_WAVE=0 / QK_SMALL=0 / QK_FUSED=0 in the environment fall back to the next more
+ * (tests/test_gpu_parity.py); QK_WAVE=0 / QK_WAVE2=0 / QK_SMALL=0 / QK_FUSED=0 in the environment fall back to the next more
  * general one, QK_FUSED=2 uses the fused sweep from bond 17, QK_FUSED_WGS=1|2 fixes its workgroups per CU.          */
 int qk_gram_values(qk_ctx* ctx, const qk_mps_set* xset, const qk_mps_set* yset, const qk_plan* plan,
                    double* values_dev, double* z_dev);

@@ -406,3 +406,118 @@ __global__ void qk_interleave_kernel(const double* __restrict__ src, double* __r
     for (long long e = threadIdx.x; e < plane; e += blockDim.x) d[e] = (v2d){re[e], im[e]};
   }
 }
+
+// ----------------------------------------------------------------------------------------
+// Wave sweep for bonds <= 32 (fp64): ONE pair per wavefront, the whole chain in registers -- no LDS, no barrier, no
+// atomics.  The generalisation of qk_sweep_wave_kernel (bonds <= 16, qk_ring.h) to 2 x 2 tiles: X is held as up to four
+// A-operand tiles XA[tk][ta] (tk: block of b, ta: block of a).  Per site, for every block tb of b':
+//     for each (ta, p):  T = sum_tk XA[tk][ta]^T B_k[tk rows, p, tb cols]          (one tile, 16 VGPRs, never stored)
+//                        N[tn] += T^T conj(A_k[ta rows, p, tn cols])   for tn = 0, 1 (raw 3M accumulators)
+//     XN[tb][tn] = combine(N[tn])                                                  (C layout = next site's XA[tk = tb][ta = tn])
+// This is the regime of the 100-qubit x 10-layer config at gamma = 0.1 (bonds <= 27) and of the reference's own runs at
+// gamma <= 0.5: most sites have one or two blocks per bond, so a multi-wave workgroup would leave most of its waves idle.
+// Site tensors come straight from the interleaved image (one 16-byte load per lane and k-step), K trimmed to the true bond.
+// ----------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64, 2) void qk_sweep_wave2_kernel(const SweepArgs g) {
+  __shared__ long long slot;
+  const int lane = threadIdx.x, j = lane & 15, q = lane >> 4;
+  const int ns = g.n_sites, n1 = ns + 1;
+  const v2d* const xdata = reinterpret_cast<const v2d*>(g.xdata);
+  const v2d* const ydata = reinterpret_cast<const v2d*>(g.ydata);
+  auto uni = [](const int v) __attribute__((always_inline)) { return __builtin_amdgcn_readfirstlane(v); };
+  auto unil = [](const long long v) __attribute__((always_inline)) {
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v);
+    const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)((unsigned long long)v >> 32));
+    return (long long)(((unsigned long long)hi << 32) | lo);
+  };
+  for (;;) {
+    if (lane == 0) slot = (long long)atomicAdd(g.counter, 1ull);
+    __syncthreads();
+    const long long p = unil(slot);
+    __syncthreads();
+    if (p >= g.npairs) break;
+    const int xi = uni(g.pairs[2 * p]), yj = uni(g.pairs[2 * p + 1]);
+    const int* const xd = g.xdims + (long long)xi * n1;
+    const int* const yd = g.ydims + (long long)yj * n1;
+    const int* const xt = g.xtrue + (long long)xi * n1;
+    const int* const yt = g.ytrue + (long long)yj * n1;
+    const int64_t* const xo = g.xoffs + (long long)xi * ns;
+    const int64_t* const yo = g.yoffs + (long long)yj * ns;
+    QkfTile XA[2][2], XN[2][2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int v = 0; v < 2; ++v) XA[u][v].re = XA[u][v].im = XN[u][v].re = XN[u][v].im = (v4d){0, 0, 0, 0};
+    XA[0][0].re[0] = (lane == 0) ? 1.0 : 0.0;  // X_0 = 1: A-operand element [k = 0][m = 0]
+    for (int k = 0; k < ns; ++k) {
+      const int a = uni(xd[k]), a2 = uni(xd[k + 1]), b = uni(yd[k]), b2 = uni(yd[k + 1]);
+      const int at = uni(xt[k]), bt = uni(yt[k]);
+      const int mt = a >> 4, kb = b >> 4, nn = a2 >> 4, nt = b2 >> 4;  // blocks of a, b, a', b' (1 or 2 each)
+      const v2d* const Ak = xdata + (unil(xo[k]) >> 1);
+      const v2d* const Bk = ydata + (unil(yo[k]) >> 1);
+#pragma unroll
+      for (int tb = 0; tb < 2; ++tb) {
+        if (tb < nt) {
+          v4d n1a[2], n2a[2], n3a[2];  // raw accumulators of X'[tb][tn]
+#pragma unroll
+          for (int tn = 0; tn < 2; ++tn) n1a[tn] = n2a[tn] = n3a[tn] = (v4d){0, 0, 0, 0};
+#pragma unroll
+          for (int ta = 0; ta < 2; ++ta) {
+            if (ta < mt) {
+              const int ka = min(4, (at - ta * TILE + 3) >> 2);  // k-steps of this block of a below the true bond
+#pragma unroll
+              for (int pp = 0; pp < 2; ++pp) {
+                // ---- T = sum_tk XA[tk][ta]^T B[tk rows, pp, tb cols]
+                v4d p1 = {0, 0, 0, 0}, p2 = {0, 0, 0, 0}, p3 = {0, 0, 0, 0};
+#pragma unroll
+                for (int tk = 0; tk < 2; ++tk) {
+                  if (tk < kb) {
+                    const int kk = min(4, (bt - tk * TILE + 3) >> 2);
+                    const v2d* const bp = Bk + ((tk * TILE + q) * 2 + pp) * b2 + tb * TILE + j;
+                    v2d f[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) f[i] = bp[i * 8 * b2];  // (rows up to the padded bond exist and are zero)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                      if (i < kk) qkf_kstep<false>(p1, p2, p3, XA[tk][ta].re[i], XA[tk][ta].im[i], f[i].x, f[i].y);
+                  }
+                }
+                QkfTile t;
+                t.re = p1 - p2, t.im = p3 - p1 - p2;
+                // ---- N[tn] += T^T conj(A[ta rows, pp, tn cols])
+#pragma unroll
+                for (int tn = 0; tn < 2; ++tn) {
+                  if (tn < nn) {
+                    const v2d* const ap = Ak + ((ta * TILE + q) * 2 + pp) * a2 + tn * TILE + j;
+                    v2d f[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) f[i] = ap[i * 8 * a2];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                      if (i < ka) qkf_kstep<true>(n1a[tn], n2a[tn], n3a[tn], t.re[i], t.im[i], f[i].x, f[i].y);
+                  }
+                }
+              }
+            }
+          }
+#pragma unroll
+          for (int tn = 0; tn < 2; ++tn) XN[tb][tn].re = n1a[tn] + n2a[tn], XN[tb][tn].im = n3a[tn] - n1a[tn] + n2a[tn];
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int v = 0; v < 2; ++v) XA[u][v] = XN[u][v];
+    }
+    {
+      // z = X_n[0][0] sits in lane 0; broadcast and stored by every lane (see qk_sweep_wave_kernel for why)
+      const double re = __longlong_as_double(unil(__double_as_longlong(XA[0][0].re[0])));
+      const double im = __longlong_as_double(unil(__double_as_longlong(XA[0][0].im[0])));
+      g.values[p] = re * re + im * im;
+      if (g.z) {
+        g.z[2 * p] = re;
+        g.z[2 * p + 1] = im;
+      }
+    }
+  }
+}

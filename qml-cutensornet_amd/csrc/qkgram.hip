@@ -11,8 +11,8 @@
 //
 //
 // Files: this one = C ABI (include/qkgram.h), packing, planner, small kernels, launches;  qk_fused.h = the site-fused
-// sweep (the fp64 hot path);  qk_ring.h = the ring sweep (complex64, very large bonds), the small-bond and the
-// one-wave sweeps;  qk_build.hip = the device MPS builder.  qk_lab.hip (experimental / diagnostic kernels) is NOT part of
+// sweep (the fp64 hot path) and the 2 x 2-tile one-wave sweep (fp64, bonds <= 32);  qk_ring.h = the ring sweep (complex64,
+// very large bonds), the LDS-resident small-bond sweep and the one-tile one-wave sweep;  qk_build.hip = the device MPS builder.  qk_lab.hip (experimental / diagnostic kernels) is NOT part of
 // libqkgram.so: it is linked only into libqklab.so (-DQK_LAB), which tools/ load for A/B measurements.
 // Written for gfx950 only: 64-lane wavefronts, 160 KiB LDS per CU, no portability layer.
 #include "qk_host.h"
@@ -425,6 +425,7 @@ static int ctx_init(qk_ctx* c, int device_id, int num_cus) {
 #endif
   if (const char* v = std::getenv("QK_SMALL")) c->small_path = std::atoi(v) != 0;
   if (const char* v = std::getenv("QK_WAVE")) c->wave_path = std::atoi(v) != 0;
+  if (const char* v = std::getenv("QK_WAVE2")) c->wave2_path = std::atoi(v) != 0;
   if (const char* v = std::getenv("QK_FUSED")) c->fused_path = std::atoi(v);
   if (const char* v = std::getenv("QK_FUSED_WGS")) c->fused_wgs = std::max(0, std::min(2, std::atoi(v)));
   if (const char* v = std::getenv("QK_WGS_PER_CU")) c->wgs_per_cu = std::max(1, std::min(4, std::atoi(v)));
@@ -770,6 +771,17 @@ extern "C" int qk_gram_values(qk_ctx* c, const qk_mps_set* xs, const qk_mps_set*
     const int wgrid = (int)std::min<long long>(np, 16ll * c->num_cus);
     qk_sweep_wave_kernel<0><<<dim3(wgrid), dim3(64), 0, c->stream>>>(a);
     launched_grid = wgrid, c->last.kernel = QK_KERNEL_WAVE;
+  } else if (!fused && c->variant == 20 && c->wave2_path && !f32 && std::max(xs->max_pad, ys->max_pad) <= 32) {
+    // every bond <= 32, fp64: a pair lives in the registers of one wavefront as 2 x 2 tiles (qk_sweep_wave2_kernel); 8 waves per CU
+    for (const qk_mps_set* m : {xs, ys}) {
+      const int rc_il = ensure_interleaved(c, const_cast<qk_mps_set*>(m));
+      if (rc_il != QK_OK) return rc_il;
+    }
+    a.xdata = xs->d_il, a.ydata = ys->d_il;
+    HIP_TRY(hipEventRecord(c->ev0, c->stream));  // the conversion above is not part of the sweep
+    const int wgrid = (int)std::min<long long>(np, 8ll * c->num_cus);
+    qk_sweep_wave2_kernel<<<dim3(wgrid), dim3(64), 0, c->stream>>>(a);
+    launched_grid = wgrid, c->last.kernel = QK_KERNEL_WAVE2;
   } else if (!fused && c->variant == 20 && c->small_path && std::max(xs->max_pad, ys->max_pad) <= 32 && lds_small <= 80 * 1024) {
     // every bond <= 32: X and T stay in LDS, only the site tensors stream (qk_sweep_small_kernel); chains too long for
     // its LDS budget (several hundred sites) take the ring kernel below
@@ -844,6 +856,7 @@ extern "C" const char* qk_kernel_name(int32_t kernel, int32_t precision) {
     case QK_KERNEL_FUSED1: return "qk_sweep_fused_kernel<12, 2, 8192, 3>";
     case QK_KERNEL_FUSED2: return "qk_sweep_fused_kernel<8, 1, 4608, 4>";
     case QK_KERNEL_RING: return f32 ? "qk_sweep_ring_kernel<float>" : "qk_sweep_ring_kernel<double>";
+    case QK_KERNEL_WAVE2: return "qk_sweep_wave2_kernel";
     case QK_KERNEL_LAB: return "(lab kernel)";
     default: return "(none)";
   }

@@ -371,7 +371,7 @@ def test_small_bond_kernel(gpu_ctx, n, chi_max, nx, ny, seed, monkeypatch):
     ys = [Q.random_mps(n, _ragged_profile(rng, n, chi_max), rng) for _ in range(ny)]
     z_ref = np.array([[R.mps_inner(x.tensors, y.tensors) for x in xs] for y in ys])
     with gpu_ctx.upload(xs) as dx, gpu_ctx.upload(ys) as dy:
-        assert max(dx.info()["max_padded_bond"], dy.info()["max_padded_bond"]) <= 32  # takes the small-bond path
+        assert max(dx.info()["max_padded_bond"], dy.info()["max_padded_bond"]) <= 32  # takes a wave sweep (fp64) / the small-bond sweep (complex64)
         z = gpu_ctx.overlaps(dx, dy)
         K = gpu_ctx.gram(dx)
         with dx.to_f32() as fx, dy.to_f32() as fy:
@@ -379,16 +379,19 @@ def test_small_bond_kernel(gpu_ctx, n, chi_max, nx, ny, seed, monkeypatch):
     assert np.abs(z - z_ref).max() < TOL
     assert np.abs(np.diag(K) - 1).max() < 1e-12 and np.abs(K - K.T).max() == 0.0
     assert np.abs(z32 - z_ref).max() < F32_TOL
-    # the general (ring) kernel on the same inputs agrees to rounding; so does the LDS-resident kernel where the
-    # register (wave) kernel was the one selected above (bonds <= 16)
-    monkeypatch.setenv("QK_WAVE", "0")
-    with engine.context(0) as ctx1, ctx1.upload(xs) as dx1, ctx1.upload(ys) as dy1:
-        z_small = ctx1.overlaps(dx1, dy1)
-    assert np.abs(z - z_small).max() < 1e-13
-    monkeypatch.setenv("QK_SMALL", "0")
-    with engine.context(0) as ctx2, ctx2.upload(xs) as dx2, ctx2.upload(ys) as dy2:
-        z_ring = ctx2.overlaps(dx2, dy2)
-    assert np.abs(z - z_ring).max() < 1e-13
+    # every other kernel that can take these sets agrees to rounding on the same inputs: the 2 x 2-tile wave sweep (where the
+    # 16-bond wave sweep was the one selected above), the LDS-resident small-bond sweep, the site-fused sweep, the ring sweep
+    seen = {gpu_ctx.stats()["kernel_name"]}
+    for env in ({"QK_WAVE": "0"}, {"QK_WAVE": "0", "QK_WAVE2": "0"}, {"QK_WAVE": "0", "QK_WAVE2": "0", "QK_SMALL": "0", "QK_FUSED": "2"},
+                {"QK_WAVE": "0", "QK_WAVE2": "0", "QK_SMALL": "0", "QK_FUSED": "0"}):
+        for k_, v_ in env.items():
+            monkeypatch.setenv(k_, v_)
+        with engine.context(0) as ctx1, ctx1.upload(xs) as dx1, ctx1.upload(ys) as dy1:
+            z_other = ctx1.overlaps(dx1, dy1)
+            seen.add(ctx1.stats()["kernel_name"])
+        assert np.abs(z - z_other).max() < 1e-13, env
+    assert {"qk_sweep_wave2_kernel", "qk_sweep_small_kernel<double>", "qk_sweep_ring_kernel<double>"} <= seen
+    assert any("fused" in name_ for name_ in seen) or max(dx.dims.max(), dy.dims.max()) <= 16
 
 
 # ------------------------------------------------------------------ randomised sweep over shapes (wave, small-bond and site-fused kernels)
@@ -506,20 +509,21 @@ def test_cfg4_real_states(gpu_ctx, monkeypatch):
 
 
 def test_cfg5_real_states(gpu_ctx, monkeypatch):
-    """cfg5's real circuit (100 qubits x 10 layers, d=4, gamma=0.1, seed 5): 8 of its 1000 states through the small-bond
-    kernel (bonds <= 32), the site-fused sweep (QK_FUSED=2) and the ring sweep (QK_SMALL=0, QK_FUSED=0)."""
+    """cfg5's real circuit (100 qubits x 10 layers, d=4, gamma=0.1, seed 5): 8 of its 1000 states through every kernel that
+    takes bonds <= 32: the 2 x 2-tile wave sweep (the default), the LDS-resident small-bond sweep (QK_WAVE2=0), the site-fused
+    sweep (QK_FUSED=2) and the ring sweep (everything else off)."""
     from qml_cutensornet_amd import engine
 
     states = _real_states(100, 10, 4, 0.1, 8)
     assert 16 < max(m.max_bond() for m in states) <= 32
     _check_real_workload(gpu_ctx, states, 3)
-    monkeypatch.setenv("QK_FUSED", "2")
-    with engine.context(0) as ctx_fused:
-        _check_real_workload(ctx_fused, states, 3)
-    monkeypatch.setenv("QK_FUSED", "0")
-    monkeypatch.setenv("QK_SMALL", "0")
-    with engine.context(0) as ctx_ring:
-        _check_real_workload(ctx_ring, states, 3)
+    assert gpu_ctx.stats()["kernel_name"] == "qk_sweep_wave2_kernel"
+    for env, name in (({"QK_WAVE2": "0"}, "small"), ({"QK_FUSED": "2"}, "fused"), ({"QK_FUSED": "0", "QK_SMALL": "0"}, "ring")):
+        for k_, v_ in env.items():
+            monkeypatch.setenv(k_, v_)
+        with engine.context(0) as ctx_other:
+            _check_real_workload(ctx_other, states, 3)
+            assert name in ctx_other.stats()["kernel_name"]
 
 
 def test_both_contraction_orders_agree(gpu_ctx):
