@@ -436,25 +436,36 @@ __global__ __launch_bounds__(64, 2) void qk_sweep_wave2_kernel(const SweepArgs g
     const long long p = unil(slot);
     __syncthreads();
     if (p >= g.npairs) break;
-    const int xi = uni(g.pairs[2 * p]), yj = uni(g.pairs[2 * p + 1]);
-    const int* const xd = g.xdims + (long long)xi * n1;
-    const int* const yd = g.ydims + (long long)yj * n1;
-    const int* const xt = g.xtrue + (long long)xi * n1;
-    const int* const yt = g.ytrue + (long long)yj * n1;
-    const int64_t* const xo = g.xoffs + (long long)xi * ns;
-    const int64_t* const yo = g.yoffs + (long long)yj * ns;
+    // per-pair tables through the scalar cache (wave-uniform addresses in the constant address space): a vector load
+    // per site and table would put its whole latency in front of the site's first tensor load
+    typedef const __attribute__((address_space(4))) int* sint_p;
+    typedef const __attribute__((address_space(4))) int64_t* slong_p;
+    const int xi = ((sint_p)g.pairs)[2 * p], yj = ((sint_p)g.pairs)[2 * p + 1];
+    const sint_p xd = (sint_p)(g.xdims + (long long)xi * n1);
+    const sint_p yd = (sint_p)(g.ydims + (long long)yj * n1);
+    const sint_p xt = (sint_p)(g.xtrue + (long long)xi * n1);
+    const sint_p yt = (sint_p)(g.ytrue + (long long)yj * n1);
+    const slong_p xo = (slong_p)(g.xoffs + (long long)xi * ns);
+    const slong_p yo = (slong_p)(g.yoffs + (long long)yj * ns);
     QkfTile XA[2][2], XN[2][2];
 #pragma unroll
     for (int u = 0; u < 2; ++u)
 #pragma unroll
       for (int v = 0; v < 2; ++v) XA[u][v].re = XA[u][v].im = XN[u][v].re = XN[u][v].im = (v4d){0, 0, 0, 0};
     XA[0][0].re[0] = (lane == 0) ? 1.0 : 0.0;  // X_0 = 1: A-operand element [k = 0][m = 0]
+    // the tables of site k + 1 are fetched while site k is swept
+    int a_nx = xd[0], b_nx = yd[0], a2_nx = xd[1], b2_nx = yd[1], at_nx = xt[0], bt_nx = yt[0];
+    long long xo_nx = xo[0], yo_nx = yo[0];
     for (int k = 0; k < ns; ++k) {
-      const int a = uni(xd[k]), a2 = uni(xd[k + 1]), b = uni(yd[k]), b2 = uni(yd[k + 1]);
-      const int at = uni(xt[k]), bt = uni(yt[k]);
+      const int a = a_nx, a2 = a2_nx, b = b_nx, b2 = b2_nx, at = at_nx, bt = bt_nx;
+      const v2d* const Ak = xdata + (xo_nx >> 1);
+      const v2d* const Bk = ydata + (yo_nx >> 1);
+      {
+        const int k1 = min(k + 1, ns - 1);
+        a_nx = a2, b_nx = b2, a2_nx = xd[k1 + 1], b2_nx = yd[k1 + 1], at_nx = xt[k1], bt_nx = yt[k1];
+        xo_nx = xo[k1], yo_nx = yo[k1];
+      }
       const int mt = a >> 4, kb = b >> 4, nn = a2 >> 4, nt = b2 >> 4;  // blocks of a, b, a', b' (1 or 2 each)
-      const v2d* const Ak = xdata + (unil(xo[k]) >> 1);
-      const v2d* const Bk = ydata + (unil(yo[k]) >> 1);
 #pragma unroll
       for (int tb = 0; tb < 2; ++tb) {
         if (tb < nt) {
