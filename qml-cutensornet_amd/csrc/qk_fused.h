@@ -408,19 +408,36 @@ __global__ void qk_interleave_kernel(const double* __restrict__ src, double* __r
 }
 
 // ----------------------------------------------------------------------------------------
-// Wave sweep for bonds <= 32 (fp64): ONE pair per wavefront, the whole chain in registers -- no LDS, no barrier, no
-// atomics.  The generalisation of qk_sweep_wave_kernel (bonds <= 16, qk_ring.h) to 2 x 2 tiles: X is held as up to four
+// Wave sweep for bonds <= 32 (fp64): ONE pair per wavefront, the whole chain in registers -- no barrier, no atomics, no
+// scratch.  The generalisation of qk_sweep_wave_kernel (bonds <= 16, qk_ring.h) to 2 x 2 tiles: X is held as up to four
 // A-operand tiles XA[tk][ta] (tk: block of b, ta: block of a).  Per site, for every block tb of b':
 //     for each (ta, p):  T = sum_tk XA[tk][ta]^T B_k[tk rows, p, tb cols]          (one tile, 16 VGPRs, never stored)
 //                        N[tn] += T^T conj(A_k[ta rows, p, tn cols])   for tn = 0, 1 (raw 3M accumulators)
 //     XN[tb][tn] = combine(N[tn])                                                  (C layout = next site's XA[tk = tb][ta = tn])
 // This is the regime of the 100-qubit x 10-layer config at gamma = 0.1 (bonds <= 27) and of the reference's own runs at
 // gamma <= 0.5: most sites have one or two blocks per bond, so a multi-wave workgroup would leave most of its waves idle.
-// Site tensors come straight from the interleaved image (one 16-byte load per lane and k-step), K trimmed to the true bond.
+// What bounds it is the stream of site tensors (8 waves per CU, each reading its own pair): with plain loads right before
+// use a wave has 4 KiB in flight and the launch sits at the latency of HBM (219 ms on that config).  So the fragments reach
+// the wave through a private 12-KiB LDS ring filled by LDS-DMA two k-step groups ahead of the matrix instructions, the per-pair
+// tables come through the scalar cache, and only the k-steps below the TRUE bond are fetched (191 -> 170 ms: the rows of zero
+// padding are a third of the image at bonds around 20).
 // ----------------------------------------------------------------------------------------
+template <int N>
+__device__ __forceinline__ void qkw_wait_vmcnt() {
+  static_assert(N >= 0 && N < 64, "vmcnt is a 6-bit field");
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+// NG > 0: the k-step groups (4 fragments of 1 KiB) reach the wave through a private LDS ring of NG groups filled by LDS-DMA,
+// NG - 1 .. NG groups ahead of the matrix instructions (the fetch side walks the same loop nest as a small scalar state
+// machine, across site boundaries).  NG = 0: plain loads into registers right before use (4 KiB in flight per wave).
+template <int NG>
 __global__ __launch_bounds__(64, 2) void qk_sweep_wave2_kernel(const SweepArgs g) {
   __shared__ long long slot;
+  __shared__ v2d ring[NG > 0 ? NG * 4 * 64 : 1];
+  typedef __attribute__((address_space(3))) void* lds_ptr_t;
   const int lane = threadIdx.x, j = lane & 15, q = lane >> 4;
+  const unsigned ring_lds = (unsigned)(uintptr_t)(lds_ptr_t)ring + (unsigned)lane * 16u;  // this lane's byte address in slot 0, fragment 0
   const int ns = g.n_sites, n1 = ns + 1;
   const v2d* const xdata = reinterpret_cast<const v2d*>(g.xdata);
   const v2d* const ydata = reinterpret_cast<const v2d*>(g.ydata);
@@ -453,6 +470,73 @@ __global__ __launch_bounds__(64, 2) void qk_sweep_wave2_kernel(const SweepArgs g
 #pragma unroll
       for (int v = 0; v < 2; ++v) XA[u][v].re = XA[u][v].im = XN[u][v].re = XN[u][v].im = (v4d){0, 0, 0, 0};
     XA[0][0].re[0] = (lane == 0) ? 1.0 : 0.0;  // X_0 = 1: A-operand element [k = 0][m = 0]
+    // ---- fetch side (NG > 0): group order = for tb, ta, p: { P1 groups tk < kb, P2 groups tn < nn }, site after site
+    int f_k = 0, f_tb = 0, f_ta = 0, f_p = 0, f_h = 0, f_slot = 0, c_slot = 0, f_ahead = 0;
+    int f_a = xd[0], f_a2 = xd[1], f_b = yd[0], f_b2 = yd[1], f_at = xt[0], f_bt = yt[0];
+    const v2d* f_A = xdata + (xo[0] >> 1);
+    const v2d* f_B = ydata + (yo[0] >> 1);
+    // fetch the next group: only its k-steps below the true bond (the rows above are zero padding; they make up a third
+    // of the image at bonds around 20).  Returns the number of fragments it asked for.
+    auto issue = [&]() __attribute__((always_inline)) {
+      if (f_k >= ns) return 0;
+      const int kb = f_b >> 4, nn = f_a2 >> 4;
+      const bool is_b = f_h < kb;
+      const int ld = is_b ? f_b2 : f_a2;
+      const int cnt = is_b ? min(4, (f_bt - f_h * TILE + 3) >> 2) : min(4, (f_at - f_ta * TILE + 3) >> 2);
+      const v2d* const base = is_b ? f_B + ((f_h * TILE) * 2 + f_p) * f_b2 + f_tb * TILE : f_A + ((f_ta * TILE) * 2 + f_p) * f_a2 + (f_h - kb) * TILE;
+      const v2d* const src = base + (q * 2) * ld + j;
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        if (i < cnt) __builtin_amdgcn_global_load_lds(src + i * 8 * ld, (lds_ptr_t)(ring + (f_slot * 4 + i) * 64), 16, 0, 0);
+      f_slot = (f_slot == NG - 1) ? 0 : f_slot + 1;
+      if (++f_h == kb + nn) {
+        f_h = 0;
+        if (++f_p == 2) {
+          f_p = 0;
+          if (++f_ta == (f_a >> 4)) {
+            f_ta = 0;
+            if (++f_tb == (f_b2 >> 4)) {
+              f_tb = 0;
+              if (++f_k < ns) {
+                f_a = f_a2, f_b = f_b2, f_a2 = xd[f_k + 1], f_b2 = yd[f_k + 1], f_at = xt[f_k], f_bt = yt[f_k];
+                f_A = xdata + (xo[f_k] >> 1), f_B = ydata + (yo[f_k] >> 1);
+              }
+            }
+          }
+        }
+      }
+      return cnt;
+    };
+    // the next group of the order above, as four fragments in registers (those above the true bond hold stale data and
+    // are not used).  f_ahead = fragments asked for behind the group that is taken.
+    auto take = [&](v2d(&f)[4]) __attribute__((always_inline)) {
+      const int more = issue();
+      switch (f_ahead + more) {  // <= 4 (NG - 1)
+        case 0: qkw_wait_vmcnt<0>(); break;
+        case 1: qkw_wait_vmcnt<1>(); break;
+        case 2: qkw_wait_vmcnt<2>(); break;
+        case 3: qkw_wait_vmcnt<3>(); break;
+        case 4: qkw_wait_vmcnt<4>(); break;
+        case 5: qkw_wait_vmcnt<5>(); break;
+        case 6: qkw_wait_vmcnt<6>(); break;
+        case 7: qkw_wait_vmcnt<7>(); break;
+        default: qkw_wait_vmcnt<8>(); break;
+      }
+      f_ahead = more;
+      // (read by hand: the compiler puts vmcnt(0) in front of every LDS read it can see next to an LDS-DMA)
+      const unsigned at = ring_lds + (unsigned)c_slot * 4096u;
+      asm volatile("ds_read_b128 %0, %1" : "=v"(f[0]) : "v"(at));
+      asm volatile("ds_read_b128 %0, %1 offset:1024" : "=v"(f[1]) : "v"(at));
+      asm volatile("ds_read_b128 %0, %1 offset:2048" : "=v"(f[2]) : "v"(at));
+      asm volatile("ds_read_b128 %0, %1 offset:3072" : "=v"(f[3]) : "v"(at));
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3])::"memory");
+      c_slot = (c_slot == NG - 1) ? 0 : c_slot + 1;
+    };
+    if constexpr (NG > 0) {
+      static_assert(NG == 0 || NG == 3, "the wait above counts the two groups behind the one taken");
+      issue();
+      f_ahead = issue();
+    }
     // the tables of site k + 1 are fetched while site k is swept
     int a_nx = xd[0], b_nx = yd[0], a2_nx = xd[1], b2_nx = yd[1], at_nx = xt[0], bt_nx = yt[0];
     long long xo_nx = xo[0], yo_nx = yo[0];
@@ -486,8 +570,11 @@ __global__ __launch_bounds__(64, 2) void qk_sweep_wave2_kernel(const SweepArgs g
                     const int kk = min(4, (bt - tk * TILE + 3) >> 2);
                     const v2d* const bp = Bk + ((tk * TILE + q) * 2 + pp) * b2 + tb * TILE + j;
                     v2d f[4];
+                    if constexpr (NG > 0) take(f);
+                    else {
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) f[i] = bp[i * 8 * b2];  // (rows up to the padded bond exist and are zero)
+                      for (int i = 0; i < 4; ++i) f[i] = bp[i * 8 * b2];  // (rows up to the padded bond exist and are zero)
+                    }
 #pragma unroll
                     for (int i = 0; i < 4; ++i)
                       if (i < kk) qkf_kstep<false>(p1, p2, p3, XA[tk][ta].re[i], XA[tk][ta].im[i], f[i].x, f[i].y);
@@ -501,8 +588,11 @@ __global__ __launch_bounds__(64, 2) void qk_sweep_wave2_kernel(const SweepArgs g
                   if (tn < nn) {
                     const v2d* const ap = Ak + ((ta * TILE + q) * 2 + pp) * a2 + tn * TILE + j;
                     v2d f[4];
+                    if constexpr (NG > 0) take(f);
+                    else {
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) f[i] = ap[i * 8 * a2];
+                      for (int i = 0; i < 4; ++i) f[i] = ap[i * 8 * a2];
+                    }
 #pragma unroll
                     for (int i = 0; i < 4; ++i)
                       if (i < ka) qkf_kstep<true>(n1a[tn], n2a[tn], n3a[tn], t.re[i], t.im[i], f[i].x, f[i].y);

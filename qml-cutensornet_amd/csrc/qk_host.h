@@ -35,6 +35,7 @@ struct qk_ctx {
                        // sweep; 0, 2, 12, 13, 14, 16, 21, 23 = other kernels kept for A/B; 9, 19 = instrumented)
   int wgs_per_cu = 2;  // resident workgroups per CU (QK_WGS_PER_CU)
   bool wave_path = true;   // fp64 sets whose bonds are all <= 16 use the one-wave-per-pair register sweep (QK_WAVE=0 opts out)
+  bool wave2_ring = true;  // ... with its k-step groups prefetched through a per-wave LDS ring (QK_WAVE2=2: plain loads)
   bool wave2_path = true;  // fp64 sets whose bonds are all <= 32 use the one-wave-per-pair sweep with 2 x 2 register tiles (QK_WAVE2=0 opts out)
   bool small_path = true;  // sets whose bonds are all <= 32 use the LDS-resident small-bond sweep (QK_SMALL=0 opts out)
   int fused_wgs = 0;       // workgroups per CU of the site-fused sweep: 0 = chosen per launch from the plan, 1 / 2 forced (QK_FUSED_WGS)

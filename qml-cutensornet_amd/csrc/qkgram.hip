@@ -169,6 +169,7 @@ extern "C" int qk_plan_create(int32_t n_sites, int32_t nx, const int32_t* x_dims
   struct Item {
     int32_t i, j;
     float cost;
+    int32_t tile = 0;
   };
   if (flags & QK_PLAN_QUADS) {
     // 2x2 blocks of pairs {i1, i2} x {j1, j2} (duos of consecutive states; the last duo of an odd set names its state
@@ -232,6 +233,7 @@ extern "C" int qk_plan_create(int32_t n_sites, int32_t nx, const int32_t* x_dims
   const int stride = n_sites + 1;
   int64_t t = 0;  // running index in the global order
   std::vector<int64_t> per_rank(world_size, 0);
+  std::vector<int32_t> tile_of;  // locality tile of each pair of this rank
   double flops = 0, padded = 0, bytes = 0, fit_two = 0;
   const int nbx = (nx + block - 1) / block, nby = (ny + block - 1) / block;
   for (int bj = 0; bj < nby; ++bj)
@@ -258,6 +260,7 @@ extern "C" int qk_plan_create(int32_t n_sites, int32_t nx, const int32_t* x_dims
         if (r == rank) {
           p->pairs.push_back(it.i);
           p->pairs.push_back(it.j);
+          tile_of.push_back(bj * nbx + bi);
           double f, fp, by, ft;
           pair_work(n_sites, x_dims + (int64_t)it.i * stride, y_dims + (int64_t)it.j * stride, &f, &fp, &by, &ft);
           flops += f, padded += fp, bytes += by, fit_two += ft;
@@ -268,7 +271,8 @@ extern "C" int qk_plan_create(int32_t n_sites, int32_t nx, const int32_t* x_dims
   // Regroup this rank's share: pairs that share the x state are made contiguous and cut into
   // groups of at most QK_GROUP (default 4) pairs -- one workgroup sweeps a group in lockstep so
   // that A_i is read once per group and the per-phase latencies are shared.  Groups are then
-  // ordered by decreasing cost (longest first for the device-side queue).
+  // ordered by decreasing cost (longest first for the device-side queue) -- inside their locality tile when the plan has
+  // tiles (`block`): the queue then walks the Gram tile by tile.
   {
     int G = 4;
     if (const char* e = std::getenv("QK_GROUP")) G = std::max(1, std::min(4, std::atoi(e)));
@@ -279,23 +283,24 @@ extern "C" int qk_plan_create(int32_t n_sites, int32_t nx, const int32_t* x_dims
       double f, fp, by;
       const int i = p->pairs[2 * q], j = p->pairs[2 * q + 1];
       pair_work(n_sites, x_dims + (int64_t)i * stride, y_dims + (int64_t)j * stride, &f, &fp, &by);
-      mine[(size_t)q] = {i, j, (float)fp};
+      mine[(size_t)q] = {i, j, (float)fp, tile_of[(size_t)q]};
     }
-    std::stable_sort(mine.begin(), mine.end(), [](const Item& u, const Item& v) { return u.i != v.i ? u.i < v.i : u.cost > v.cost; });
+    std::stable_sort(mine.begin(), mine.end(), [](const Item& u, const Item& v) { return u.tile != v.tile ? u.tile < v.tile : u.i != v.i ? u.i < v.i : u.cost > v.cost; });
     struct Grp {
       int64_t start;
       int count;
       double cost;
+      int32_t tile;
     };
     std::vector<Grp> grp;
     for (int64_t q = 0; q < np;) {
       int c = 1;
       double cost = mine[(size_t)q].cost;
-      while (c < G && q + c < np && mine[(size_t)(q + c)].i == mine[(size_t)q].i) cost += mine[(size_t)(q + c)].cost, ++c;
-      grp.push_back({q, c, cost});
+      while (c < G && q + c < np && mine[(size_t)(q + c)].i == mine[(size_t)q].i && mine[(size_t)(q + c)].tile == mine[(size_t)q].tile) cost += mine[(size_t)(q + c)].cost, ++c;
+      grp.push_back({q, c, cost, mine[(size_t)q].tile});
       q += c;
     }
-    std::stable_sort(grp.begin(), grp.end(), [](const Grp& u, const Grp& v) { return u.cost > v.cost; });
+    std::stable_sort(grp.begin(), grp.end(), [](const Grp& u, const Grp& v) { return u.tile != v.tile ? u.tile < v.tile : u.cost > v.cost; });
     p->pairs.clear();
     for (const Grp& gq : grp) {
       p->groups.push_back((int32_t)(p->pairs.size() / 2));
@@ -425,7 +430,7 @@ static int ctx_init(qk_ctx* c, int device_id, int num_cus) {
 #endif
   if (const char* v = std::getenv("QK_SMALL")) c->small_path = std::atoi(v) != 0;
   if (const char* v = std::getenv("QK_WAVE")) c->wave_path = std::atoi(v) != 0;
-  if (const char* v = std::getenv("QK_WAVE2")) c->wave2_path = std::atoi(v) != 0;
+  if (const char* v = std::getenv("QK_WAVE2")) c->wave2_path = std::atoi(v) != 0, c->wave2_ring = std::atoi(v) != 2;
   if (const char* v = std::getenv("QK_FUSED")) c->fused_path = std::atoi(v);
   if (const char* v = std::getenv("QK_FUSED_WGS")) c->fused_wgs = std::max(0, std::min(2, std::atoi(v)));
   if (const char* v = std::getenv("QK_WGS_PER_CU")) c->wgs_per_cu = std::max(1, std::min(4, std::atoi(v)));
@@ -780,7 +785,8 @@ extern "C" int qk_gram_values(qk_ctx* c, const qk_mps_set* xs, const qk_mps_set*
     a.xdata = xs->d_il, a.ydata = ys->d_il;
     HIP_TRY(hipEventRecord(c->ev0, c->stream));  // the conversion above is not part of the sweep
     const int wgrid = (int)std::min<long long>(np, 8ll * c->num_cus);
-    qk_sweep_wave2_kernel<<<dim3(wgrid), dim3(64), 0, c->stream>>>(a);
+    if (c->wave2_ring) qk_sweep_wave2_kernel<3><<<dim3(wgrid), dim3(64), 0, c->stream>>>(a);
+    else qk_sweep_wave2_kernel<0><<<dim3(wgrid), dim3(64), 0, c->stream>>>(a);
     launched_grid = wgrid, c->last.kernel = QK_KERNEL_WAVE2;
   } else if (!fused && c->variant == 20 && c->small_path && std::max(xs->max_pad, ys->max_pad) <= 32 && lds_small <= 80 * 1024) {
     // every bond <= 32: X and T stay in LDS, only the site tensors stream (qk_sweep_small_kernel); chains too long for
