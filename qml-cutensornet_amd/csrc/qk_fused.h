@@ -259,9 +259,10 @@ __global__ __launch_bounds__(64 * NW, WPS) void qk_sweep_fused_kernel(const Swee
       const int a = g.xdims[(long long)xi * n1 + e], a2 = g.xdims[(long long)xi * n1 + e + 1];
       const int b = g.ydims[(long long)yj * n1 + e], b2 = g.ydims[(long long)yj * n1 + e + 1];
       const int mt = a / TILE, nt = b2 / TILE;
-      // an item is (ta, tb, p): 2 mt nt of them.  LDS-resident site: X and X' fit the buffer and ONE round holds all items;
+      // an item is (ta, tb, p): 2 mt nt of them.  LDS-resident site: X and X' fit the buffer and either ONE round holds all items
+      // (X' may then overwrite X) or X and X' fit side by side (any number of rounds: X stays intact);
       // otherwise X' is built in strips of W blocks of b' (the strip's rows must fit the LDS), items in rounds of NW * S
-      const int small = a * b <= XCAP && a2 * b2 <= XCAP && 2 * mt * nt <= NW * S;
+      const int small = a * b <= XCAP && a2 * b2 <= XCAP && (2 * mt * nt <= NW * S || a * b + a2 * b2 <= XCAP);
       const int W = small ? nt : max(1, min(nt, XCAP / (TILE * a2)));
       rec[3 * e] = (v4i){a, a2, b, b2};
       rec[3 * e + 1] = (v4i){g.xtrue[(long long)xi * n1 + e], (g.ytrue[(long long)yj * n1 + e] + 3) >> 2, W, small};
@@ -333,8 +334,8 @@ __global__ __launch_bounds__(64 * NW, WPS) void qk_sweep_fused_kernel(const Swee
           if (xg) phase1((const v2d*)Gc);
           else phase1((const lds_v2d*)(XL + xb));
           QKF_STAMP(2);  // phase 1
-          if (small) {
-            qk_lds_barrier();  // ping-pong: X' is zero everywhere; in place: every wave has read X, it becomes X'
+          if (small && r0 == 0) {
+            qk_lds_barrier();  // ping-pong: X' is zero everywhere; in place (one round): every wave has read X, it becomes X'
             if (!pingpong) {
               for (int e = tid; e < n_out; e += NT) XL[e] = (v2d){0.0, 0.0};
               qk_lds_barrier();
@@ -391,6 +392,284 @@ __global__ __launch_bounds__(64 * NW, WPS) void qk_sweep_fused_kernel(const Swee
     for (int i = 0; i < 8; ++i) atomicAdd(g.prof + i, pf[i]);
   }
 #endif
+}
+
+// ----------------------------------------------------------------------------------------
+// The DUAL form of the site-fused sweep: the unit of work is a pair of tiles T[ta, p, tb0], T[ta, p, tb0 + 1] (same rows
+// of X and of A, neighbouring column blocks of B).  Phase 1 reads each X fragment once for both tiles; phase 2 reads each
+// fragment of A once and feeds it to both tiles: half the A fragments, half the X fragments and half the per-item set-up
+// of the single-tile form for the same matrix work.  One pair per wave and round, so there are no slots to rotate.
+// ----------------------------------------------------------------------------------------
+template <bool HAS1, typename XPtr>
+__device__ __forceinline__ void qkf_p1_dual(QkfTile& t0, QkfTile& t1, v2d (&fr)[4], v2d (&fs)[4], const bool primed, QkfStream cur, XPtr xp, unsigned xoff, const int xstep, const int nks,
+                                            const QkfStream nxt) {
+  v4d p1 = {0, 0, 0, 0}, p2 = {0, 0, 0, 0}, p3 = {0, 0, 0, 0}, r1 = {0, 0, 0, 0}, r2 = {0, 0, 0, 0}, r3 = {0, 0, 0, 0};
+  v2d fx[4];
+  if (!primed) {
+    qkf_load4(fr, cur);
+    if (HAS1) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) fs[i] = qkf_ldg(cur.base + i * cur.step, cur.off + TILE);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) fx[i] = qkf_ldx(xp + i * xstep, xoff);
+  const int ng = (nks + 3) >> 2, last = nks - 4 * (ng - 1);  // k-steps of the last group: 1..4
+  QKF_PRIO_LO();
+#pragma unroll 1
+  for (int gq = 0; gq + 1 < ng; ++gq) {
+    cur.off += 4 * cur.step, xoff += 4 * xstep;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      qkf_kstep<false>(p1, p2, p3, fx[i].x, fx[i].y, fr[i].x, fr[i].y);
+      if (HAS1) qkf_kstep<false>(r1, r2, r3, fx[i].x, fx[i].y, fs[i].x, fs[i].y);
+      fr[i] = qkf_ldg(cur.base + i * cur.step, cur.off);
+      if (HAS1) fs[i] = qkf_ldg(cur.base + i * cur.step, cur.off + TILE);
+      fx[i] = qkf_ldx(xp + i * xstep, xoff);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    if (i < last) {
+      qkf_kstep<false>(p1, p2, p3, fx[i].x, fx[i].y, fr[i].x, fr[i].y);
+      if (HAS1) qkf_kstep<false>(r1, r2, r3, fx[i].x, fx[i].y, fs[i].x, fs[i].y);
+    }
+    fr[i] = qkf_ldg(nxt.base + i * nxt.step, nxt.off);  // the first group of this pair's phase 2 (one stream: A)
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  QKF_PRIO_HI();
+  t0.re = p1 - p2, t0.im = p3 - p1 - p2;
+  if (HAS1) t1.re = r1 - r2, t1.im = r3 - r1 - r2;
+}
+
+// Phase 2 of a pair of tiles: X'[tb0 rows | tb0 + 1 rows, tn cols] += T0^T | T1^T conj(A[16 ta + ., p, 16 tn + .]).  `nxt` is the
+// wave's next phase-1 stream (NXT_P1: both column blocks are loaded, the second one at + n1 elements) or a dummy.
+template <bool FULL, bool HAS1>
+__device__ __forceinline__ void qkf_p2_dual(const QkfTile& t0, const QkfTile& t1, v2d (&fr)[4], v2d (&fs)[4], QkfStream cur, const int a2, const int nn, const int kmax, lds_v2d* xo, const int q,
+                                            const int j, const QkfStream nxt, const bool nxt_p1, const unsigned n1) {
+  __attribute__((address_space(3))) double* d = (__attribute__((address_space(3))) double*)(xo + q * a2 + j);
+#pragma unroll 1
+  for (int tn = 0; tn < nn; ++tn) {
+    v4d p1 = {0, 0, 0, 0}, p2 = {0, 0, 0, 0}, p3 = {0, 0, 0, 0}, r1 = {0, 0, 0, 0}, r2 = {0, 0, 0, 0}, r3 = {0, 0, 0, 0};
+    const bool fin = tn + 1 == nn;
+    const v2d* const rb = fin ? nxt.base : cur.base;
+    const int rs = fin ? nxt.step : cur.step;
+    cur.off = fin ? nxt.off : cur.off + TILE;
+    QKF_PRIO_LO();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      if (FULL || i < kmax) {
+        qkf_kstep<true>(p1, p2, p3, t0.re[i], t0.im[i], fr[i].x, fr[i].y);
+        if (HAS1) qkf_kstep<true>(r1, r2, r3, t1.re[i], t1.im[i], fr[i].x, fr[i].y);
+      }
+      fr[i] = qkf_ldg(rb + i * rs, cur.off);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (fin && nxt_p1) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) fs[i] = qkf_ldg(rb + i * rs, cur.off + n1);
+    }
+    QKF_PRIO_HI();
+    {
+      const v4d re = p1 + p2, im = p3 - p1 + p2;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        __hip_atomic_fetch_add(d + (long)r * 8 * a2, re[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __hip_atomic_fetch_add(d + (long)r * 8 * a2 + 1, im[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      }
+    }
+    if (HAS1) {
+      const v4d re = r1 + r2, im = r3 - r1 + r2;
+      __attribute__((address_space(3))) double* const d1 = d + (long)2 * TILE * a2;  // 16 rows further down
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        __hip_atomic_fetch_add(d1 + (long)r * 8 * a2, re[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __hip_atomic_fetch_add(d1 + (long)r * 8 * a2 + 1, im[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      }
+    }
+    d += 2 * TILE;
+  }
+}
+
+template <int NW, int XCAP, int WPS>  // waves per workgroup (a round holds NW pairs of tiles); elements of the LDS X buffer; waves per SIMD (register budget)
+__global__ __launch_bounds__(64 * NW, WPS) void qk_sweep_fused_dual_kernel(const SweepArgs g) {
+  constexpr int NT = 64 * NW;
+  extern __shared__ __attribute__((aligned(16))) double lds_raw[];
+  lds_v2d* const XL = (lds_v2d*)lds_raw;
+  long long* const slot = reinterpret_cast<long long*>(lds_raw + 2 * XCAP);
+  const v2d* const xdata = reinterpret_cast<const v2d*>(g.xdata);
+  const v2d* const ydata = reinterpret_cast<const v2d*>(g.ydata);
+  v2d* const G0 = reinterpret_cast<v2d*>(g.scratch) + (long long)blockIdx.x * 2 * g.x_plane;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int j = lane & 15, q = lane >> 4;
+  const int ns = g.n_sites, n1 = ns + 1;
+  lds_v4i* const rec = (lds_v4i*)(slot + 2);  // per-site records as in qk_sweep_fused_kernel
+  long long* const m_off = reinterpret_cast<long long*>(slot + 2) + 6 * (long long)ns;
+  auto rfl = [&](const int v) __attribute__((always_inline)) { return __builtin_amdgcn_readfirstlane(v); };
+  auto ldl = [&](const long long* p_) __attribute__((always_inline)) {
+    const long long v = *p_;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v);
+    const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)((unsigned long long)v >> 32));
+    return (long long)(((unsigned long long)hi << 32) | lo);
+  };
+  auto site = [&](const int k) __attribute__((always_inline)) {
+    const v4i r0 = rec[3 * k], r1 = rec[3 * k + 1], r2 = rec[3 * k + 2];
+    QkfSite s;
+    s.a = rfl(r0.x), s.a2 = rfl(r0.y), s.b = rfl(r0.z), s.b2 = rfl(r0.w);
+    s.at = rfl(r1.x), s.nks = rfl(r1.y), s.W = rfl(r1.z), s.small = rfl(r1.w) != 0;
+    s.inv = rfl(r2.x);
+    s.mt = s.a / TILE, s.nt = s.b2 / TILE, s.nn = s.a2 / TILE;
+    s.Ak = xdata + ldl(m_off + 2 * k);
+    s.Bk = ydata + ldl(m_off + 2 * k + 1);
+    return s;
+  };
+  // the streams of pair `v` of a strip starting at block s0 (v = 2 (tp * mt + ta) + p; column blocks s0 + 2 tp, + 1)
+  auto b_stream = [&](const QkfSite& s, const int s0, const int v) __attribute__((always_inline)) {
+    const int pp = v & 1, u = v >> 1, tp = (u * s.inv) >> 20;
+    return QkfStream{s.Bk + pp * s.b2, (unsigned)((q * 2) * s.b2 + (s0 + 2 * tp) * TILE + j), 8 * s.b2};
+  };
+  auto a_stream = [&](const QkfSite& s, const int v) __attribute__((always_inline)) {
+    const int pp = v & 1, u = v >> 1, tp = (u * s.inv) >> 20, ta = u - tp * s.mt;
+    return QkfStream{s.Ak + pp * s.a2, (unsigned)(((ta * TILE + q) * 2) * s.a2 + j), 8 * s.a2};
+  };
+  for (;;) {
+    if (tid == 0) *slot = (long long)atomicAdd(g.counter, 1ull);
+    __syncthreads();
+    const long long p = *slot;
+    __syncthreads();
+    if (p >= g.npairs) break;
+    const int xi = g.pairs[2 * p], yj = g.pairs[2 * p + 1];
+    for (int e = tid; e < ns; e += NT) {
+      const int a = g.xdims[(long long)xi * n1 + e], a2 = g.xdims[(long long)xi * n1 + e + 1];
+      const int b = g.ydims[(long long)yj * n1 + e], b2 = g.ydims[(long long)yj * n1 + e + 1];
+      const int mt = a / TILE, nt = b2 / TILE;
+      // a unit is (ta, tp, p): 2 mt ceil(nt / 2) pairs of tiles.  LDS-resident site: X and X' fit the buffer and ONE round holds
+      // all pairs, or they fit side by side; otherwise X' is built in strips of W blocks of b', pairs in rounds of NW
+      const int small = a * b <= XCAP && a2 * b2 <= XCAP && (2 * mt * ((nt + 1) / 2) <= NW || a * b + a2 * b2 <= XCAP);
+      const int W = small ? nt : max(1, min(nt, XCAP / (TILE * a2)));  // (an odd strip ends in a single tile)
+      rec[3 * e] = (v4i){a, a2, b, b2};
+      rec[3 * e + 1] = (v4i){g.xtrue[(long long)xi * n1 + e], (g.ytrue[(long long)yj * n1 + e] + 3) >> 2, W, small};
+      rec[3 * e + 2] = (v4i){((1 << 20) + mt - 1) / mt, 0, 0, 0};
+      m_off[2 * e] = g.xoffs[(long long)xi * ns + e] >> 1;
+      m_off[2 * e + 1] = g.yoffs[(long long)yj * ns + e] >> 1;
+    }
+    for (int e = tid; e < TILE * TILE; e += NT) XL[e] = (v2d){e == 0 ? 1.0 : 0.0, 0.0};
+    __syncthreads();
+    bool xg = false;
+    int cur = 0, xb = 0;
+    QkfTile T0, T1;
+    v2d fr[4], fs[4];     // the fragment registers of the wave's global streams (fs: the second column block of phase 1)
+    bool primed = false;  // fr / fs hold the first group of the wave's next pair of tiles
+    QkfSite sn = site(0);
+    for (int k = 0; k < ns; ++k) {
+      const QkfSite sc = sn;
+      if (k + 1 < ns) sn = site(k + 1);
+      const int a = sc.a, a2 = sc.a2, b = sc.b, mt = sc.mt, nt = sc.nt, W = sc.W;
+      const bool small = sc.small;
+      v2d* const Gc = G0 + (long long)cur * g.x_plane;
+      v2d* const Gn = G0 + (long long)(cur ^ 1) * g.x_plane;
+      if (small && xg) {
+        for (int e = tid; e < a * b; e += NT) XL[e] = Gc[e];
+        __syncthreads();
+        xg = false, xb = 0;
+      } else if (!small && !xg) {
+        for (int e = tid; e < a * b; e += NT) Gc[e] = XL[xb + e];
+        __syncthreads();
+        xg = true;
+      }
+      const int n_out = sc.b2 * a2;
+      const bool pingpong = small && a * b + n_out <= XCAP;
+      const int ob = !small ? 0 : pingpong ? (xb == 0 ? XCAP - n_out : 0) : 0;
+      if (pingpong)
+        for (int e = tid; e < n_out; e += NT) XL[ob + e] = (v2d){0.0, 0.0};
+      for (int s0 = 0; s0 < nt; s0 += W) {
+        const int w = min(W, nt - s0), units = 2 * mt * ((w + 1) >> 1);
+        if (!small) {
+          for (int e = tid; e < w * TILE * a2; e += NT) XL[e] = (v2d){0.0, 0.0};
+          qk_lds_barrier();
+        }
+        for (int r0 = 0; r0 < units; r0 += NW) {  // (one round on the LDS-resident path)
+          const int v = r0 + wave;
+          const bool mine = v < units;
+          const int u = v >> 1, tp = (u * sc.inv) >> 20, ta = u - tp * mt;
+          const bool has1 = 2 * tp + 1 < w;
+          if (mine) {
+            const QkfStream bs = b_stream(sc, s0, v), as = a_stream(sc, v);
+            const unsigned xoff = (unsigned)(q * a + ta * TILE + j);
+            if (xg) {
+              if (has1) qkf_p1_dual<true>(T0, T1, fr, fs, primed, bs, (const v2d*)Gc, xoff, 4 * a, sc.nks, as);
+              else qkf_p1_dual<false>(T0, T1, fr, fs, primed, bs, (const v2d*)Gc, xoff, 4 * a, sc.nks, as);
+            } else {
+              if (has1) qkf_p1_dual<true>(T0, T1, fr, fs, primed, bs, (const lds_v2d*)(XL + xb), xoff, 4 * a, sc.nks, as);
+              else qkf_p1_dual<false>(T0, T1, fr, fs, primed, bs, (const lds_v2d*)(XL + xb), xoff, 4 * a, sc.nks, as);
+            }
+          }
+          if (small && r0 == 0) {
+            qk_lds_barrier();  // ping-pong: X' is zero everywhere; in place (one round): every wave has read X, it becomes X'
+            if (!pingpong) {
+              for (int e = tid; e < n_out; e += NT) XL[e] = (v2d){0.0, 0.0};
+              qk_lds_barrier();
+            }
+          }
+          if (mine) {
+            const int kmax = min(4, (sc.at - ta * TILE + 3) >> 2);
+            // what the wave does next: its pair of the next round of this strip, of the first round of the next strip, or of
+            // the next site (strip 0, round 0) -- if it has one there
+            QkfStream nxt = a_stream(sc, v);
+            bool np1 = false;
+            unsigned nd1 = 0;
+            if (v + NW < units) {
+              nxt = b_stream(sc, s0, v + NW), np1 = true;
+              nd1 = (2 * ((((v + NW) >> 1) * sc.inv) >> 20) + 1 < w) ? TILE : 0;
+            } else if (s0 + W < nt) {
+              const int w2 = min(W, nt - s0 - W);
+              if (wave < 2 * mt * ((w2 + 1) >> 1)) {
+                nxt = b_stream(sc, s0 + W, wave), np1 = true;
+                nd1 = (2 * (((wave >> 1) * sc.inv) >> 20) + 1 < w2) ? TILE : 0;
+              }
+            } else if (k + 1 < ns) {
+              const int w2 = min(sn.W, sn.nt);
+              if (wave < 2 * sn.mt * ((w2 + 1) >> 1)) {
+                nxt = b_stream(sn, 0, wave), np1 = true;
+                nd1 = (2 * (((wave >> 1) * sn.inv) >> 20) + 1 < w2) ? TILE : 0;
+              }
+            }
+            lds_v2d* const xo = XL + ob + (2 * tp) * TILE * a2;
+            if (has1) {
+              if (kmax == 4) qkf_p2_dual<true, true>(T0, T1, fr, fs, a_stream(sc, v), a2, sc.nn, 4, xo, q, j, nxt, np1, nd1);
+              else qkf_p2_dual<false, true>(T0, T1, fr, fs, a_stream(sc, v), a2, sc.nn, kmax, xo, q, j, nxt, np1, nd1);
+            } else {
+              if (kmax == 4) qkf_p2_dual<true, false>(T0, T1, fr, fs, a_stream(sc, v), a2, sc.nn, 4, xo, q, j, nxt, np1, nd1);
+              else qkf_p2_dual<false, false>(T0, T1, fr, fs, a_stream(sc, v), a2, sc.nn, kmax, xo, q, j, nxt, np1, nd1);
+            }
+            primed = np1;
+          }
+        }
+        qk_lds_barrier();  // the strip of X' is complete
+        if (!small && nt > W) {
+          for (int e = tid; e < w * TILE * a2; e += NT) Gn[(long long)s0 * TILE * a2 + e] = XL[e];
+          __syncthreads();
+        }
+      }
+      if (!small) {
+        if (nt > W) cur ^= 1;
+        else xg = false, xb = 0;
+      } else {
+        xb = ob;
+      }
+    }
+    if (tid == 0) {
+      const v2d zz = xg ? G0[(long long)cur * g.x_plane] : (v2d)XL[xb];
+      g.values[p] = zz.x * zz.x + zz.y * zz.y;
+      if (g.z) {
+        g.z[2 * p] = zz.x;
+        g.z[2 * p + 1] = zz.y;
+      }
+    }
+    __syncthreads();
+  }
 }
 
 // split planes (re | im) of a set image -> interleaved complex128, same offsets; one workgroup per (state, site)

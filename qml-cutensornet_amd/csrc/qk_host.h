@@ -66,6 +66,7 @@ struct qk_plan {
   std::vector<int32_t> groups;  // (first pair, count): runs of <= group pairs that share the x state
   int group = 1;
   qk_stats stats{};
+  double big_share = 0.0;  // share of this rank's padded work in sites whose X or X' does not fit the fused sweep's larger LDS buffer
   double fit_two = 1.0;  // share of this rank's padded work in sites whose X and X' fit the fused sweep's smaller LDS buffer
   // lazily uploaded copy
   qk_ctx* up_ctx = nullptr;

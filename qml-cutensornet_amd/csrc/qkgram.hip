@@ -119,8 +119,13 @@ static constexpr int QKF_XCAP_ONE = 8192, QKF_XCAP_TWO = 4608;  // elements of t
 #endif
 #define QKF_KERNEL_ONE qk_sweep_fused_kernel<QKF_ONE_NW, QKF_ONE_S, QKF_XCAP_ONE, QKF_ONE_WPS>
 #define QKF_KERNEL_TWO qk_sweep_fused_kernel<QKF_TWO_NW, QKF_TWO_S, QKF_XCAP_TWO, QKF_TWO_WPS>
-static void pair_work(int n, const int32_t* a, const int32_t* b, double* flops, double* padded, double* bytes, double* fit_two = nullptr) {
-  double f = 0, fp = 0, by = 0, ft = 0;
+#ifndef QKF_DUAL_NW
+#define QKF_DUAL_NW 12
+#define QKF_DUAL_WPS 3
+#endif
+#define QKF_KERNEL_DUAL qk_sweep_fused_dual_kernel<QKF_DUAL_NW, QKF_XCAP_ONE, QKF_DUAL_WPS>
+static void pair_work(int n, const int32_t* a, const int32_t* b, double* flops, double* padded, double* bytes, double* fit_two = nullptr, double* big = nullptr) {
+  double f = 0, fp = 0, by = 0, ft = 0, bg = 0;
   for (int k = 0; k < n; ++k) {
     const double a0 = a[k], a1 = a[k + 1], b0 = b[k], b1 = b[k + 1];
     const double f1 = a0 * b0 * 2 * b1 + 2 * a0 * a1 * b1;
@@ -128,10 +133,12 @@ static void pair_work(int n, const int32_t* a, const int32_t* b, double* flops, 
     f += 8 * std::min(f1, f2);
     const double A0 = pad16(a[k]), A1 = pad16(a[k + 1]), B0 = pad16(b[k]), B1 = pad16(b[k + 1]);
     fp += 8 * (A0 * B0 * 2 * B1 + 2 * A0 * A1 * B1);
+    if (A0 * B0 > QKF_XCAP_ONE || A1 * B1 > QKF_XCAP_ONE) bg += 8 * (A0 * B0 * 2 * B1 + 2 * A0 * A1 * B1);  // X or X' does not fit the larger buffer: a strip site
     if (A0 * B0 <= QKF_XCAP_TWO && A1 * B1 <= QKF_XCAP_TWO) ft += 8 * (A0 * B0 * 2 * B1 + 2 * A0 * A1 * B1);  // X and X' of this site fit the smaller buffer
     by += 16.0 * 2 * (a0 * a1 + b0 * b1);
   }
   if (fit_two) *fit_two = ft;
+  if (big) *big = bg;
   *flops = f;
   *padded = fp;
   *bytes = by + 8;
@@ -234,7 +241,7 @@ extern "C" int qk_plan_create(int32_t n_sites, int32_t nx, const int32_t* x_dims
   int64_t t = 0;  // running index in the global order
   std::vector<int64_t> per_rank(world_size, 0);
   std::vector<int32_t> tile_of;  // locality tile of each pair of this rank
-  double flops = 0, padded = 0, bytes = 0, fit_two = 0;
+  double flops = 0, padded = 0, bytes = 0, fit_two = 0, big = 0;
   const int nbx = (nx + block - 1) / block, nby = (ny + block - 1) / block;
   for (int bj = 0; bj < nby; ++bj)
     for (int bi = 0; bi < nbx; ++bi) {
@@ -261,9 +268,9 @@ extern "C" int qk_plan_create(int32_t n_sites, int32_t nx, const int32_t* x_dims
           p->pairs.push_back(it.i);
           p->pairs.push_back(it.j);
           tile_of.push_back(bj * nbx + bi);
-          double f, fp, by, ft;
-          pair_work(n_sites, x_dims + (int64_t)it.i * stride, y_dims + (int64_t)it.j * stride, &f, &fp, &by, &ft);
-          flops += f, padded += fp, bytes += by, fit_two += ft;
+          double f, fp, by, ft, bg;
+          pair_work(n_sites, x_dims + (int64_t)it.i * stride, y_dims + (int64_t)it.j * stride, &f, &fp, &by, &ft, &bg);
+          flops += f, padded += fp, bytes += by, fit_two += ft, big += bg;
         }
         ++t;
       }
@@ -316,6 +323,7 @@ extern "C" int qk_plan_create(int32_t n_sites, int32_t nx, const int32_t* x_dims
   p->stats.pairs = (int64_t)p->pairs.size() / 2;
   p->stats.flops = flops, p->stats.padded_flops = padded, p->stats.bytes = bytes;
   p->fit_two = padded > 0 ? fit_two / padded : 1.0;
+  p->big_share = padded > 0 ? big / padded : 0.0;
   *out = p;
   return QK_OK;
 }
@@ -421,6 +429,7 @@ static int ctx_init(qk_ctx* c, int device_id, int num_cus) {
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(qk_sweep_small_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(QKF_KERNEL_ONE), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(QKF_KERNEL_TWO), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(QKF_KERNEL_DUAL), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
 #ifdef QK_LAB  // libqklab.so only: the experimental kernels of qk_lab.hip, selectable with QK_VARIANT
   {
     const int rc = qk_lab_init(c);
@@ -803,9 +812,14 @@ extern "C" int qk_gram_values(qk_ctx* c, const qk_mps_set* xs, const qk_mps_set*
     a.xdata = xs->d_il, a.ydata = ys->d_il;
     a.x_plane = (long long)xs->max_pad * ys->max_pad;  // complex elements per global X buffer (two per workgroup)
     HIP_TRY(hipEventRecord(c->ev0, c->stream));        // the conversion above is not part of the sweep
+    // the dual form (pairs of tiles per wave) pays on sites that run in strips -- uniform bonds 128 / 192 / 256: +8 / +5 / +15 % --
+    // and costs on the small ones (bonds 48: -9 %; the 60-qubit x 6-layer headline set, 11 % of its work in strip sites: -14 %)
+    const char* dual_env = std::getenv("QK_FUSED_DUAL");
+    const bool dual = !fused_two && (dual_env ? std::atoi(dual_env) != 0 : plan->big_share >= 0.5);
     if (fused_two) QKF_KERNEL_TWO<<<dim3(grid), dim3(64 * QKF_TWO_NW), lds_fused, c->stream>>>(a);
+    else if (dual) QKF_KERNEL_DUAL<<<dim3(grid), dim3(64 * QKF_DUAL_NW), lds_fused, c->stream>>>(a);
     else QKF_KERNEL_ONE<<<dim3(grid), dim3(64 * QKF_ONE_NW), lds_fused, c->stream>>>(a);
-    c->last.kernel = fused_two ? QK_KERNEL_FUSED2 : QK_KERNEL_FUSED1;
+    c->last.kernel = fused_two ? QK_KERNEL_FUSED2 : dual ? QK_KERNEL_FUSED_DUAL : QK_KERNEL_FUSED1;
   } else if (f32) {  // complex64 sweep: the ring kernel on fp32 planes; QK_VARIANT does not apply
     qk_sweep_ring_kernel<float><<<dim3(grid), dim3(512), lds_ring, c->stream>>>(a);
     c->last.kernel = QK_KERNEL_RING;
@@ -863,6 +877,7 @@ extern "C" const char* qk_kernel_name(int32_t kernel, int32_t precision) {
     case QK_KERNEL_FUSED2: return "qk_sweep_fused_kernel<8, 1, 4608, 4>";
     case QK_KERNEL_RING: return f32 ? "qk_sweep_ring_kernel<float>" : "qk_sweep_ring_kernel<double>";
     case QK_KERNEL_WAVE2: return "qk_sweep_wave2_kernel";
+    case QK_KERNEL_FUSED_DUAL: return "qk_sweep_fused_dual_kernel<12, 8192, 3>";
     case QK_KERNEL_LAB: return "(lab kernel)";
     default: return "(none)";
   }

@@ -576,3 +576,50 @@ def test_bonds_beyond_the_fused_sweep_take_the_ring_sweep(gpu_ctx):
     with gpu_ctx.upload(xs[1:]) as dy:  # the same state alone: the fused sweep
         gpu_ctx.overlaps(dy)
         assert "fused" in gpu_ctx.stats()["kernel_name"]
+
+
+@pytest.mark.parametrize("n,chi_max,nx,ny,seed", [(14, 40, 3, 3, 1), (18, 100, 3, 2, 2), (20, 150, 2, 3, 3), (22, 260, 2, 2, 4)])
+def test_dual_form_of_the_fused_sweep(gpu_ctx, n, chi_max, nx, ny, seed, monkeypatch):
+    """qk_sweep_fused_dual_kernel (pairs of tiles per wave: sets dominated by strip sites select it on their own): against the
+    oracle on ragged sets of every site class -- LDS-resident in place and ping-pong, single and several strips, odd strip
+    widths and odd tile counts (single tiles at the end) -- and against the single-tile form on the same inputs."""
+    import qml_cutensornet_amd as Q
+    from qml_cutensornet_amd import engine
+    from oracle import restatement as R
+
+    rng = np.random.default_rng(seed)
+
+    def profile():  # ragged, but every inner bond at least a third of the cap
+        chi = [1]
+        for k in range(1, n):
+            cap = min(2 ** min(k, n - k, 20), chi_max, 2 * chi[-1])
+            chi.append(int(rng.integers(min(max(1, chi_max // 3), cap), cap + 1)))
+        chi.append(1)
+        for k in range(n - 1, 0, -1):
+            chi[k] = min(chi[k], 2 * chi[k + 1])
+        return chi
+
+    xs = [Q.random_mps(n, profile(), rng) for _ in range(nx)]
+    ys = [Q.random_mps(n, profile(), rng) for _ in range(ny)]
+    z_ref = np.array([[R.mps_inner(x.tensors, y.tensors) for x in xs] for y in ys])
+    out = {}
+    for dual in ("1", "0"):
+        monkeypatch.setenv("QK_FUSED_DUAL", dual)
+        monkeypatch.setenv("QK_FUSED_WGS", "1")
+        monkeypatch.setenv("QK_FUSED", "2")  # (the fused sweep also for sets whose bonds happen to stay <= 32)
+        with engine.context(0) as ctx1, ctx1.upload(xs) as dx, ctx1.upload(ys) as dy:
+            out[dual] = ctx1.overlaps(dx, dy)
+            assert ("dual" in ctx1.stats()["kernel_name"]) == (dual == "1")
+    assert np.abs(out["1"] - z_ref).max() < TOL
+    assert np.abs(out["1"] - out["0"]).max() < 1e-13
+    # uniform large bonds: most of the work sits in strip sites, the plan picks the dual form by itself
+    monkeypatch.delenv("QK_FUSED_DUAL")
+    monkeypatch.delenv("QK_FUSED_WGS")
+    monkeypatch.delenv("QK_FUSED")
+    if seed == 1:
+        big = [Q.random_mps(16, [min(2 ** min(k, 16 - k), 112) for k in range(17)], rng) for _ in range(3)]
+        with engine.context(0) as ctx1, ctx1.upload(big) as db:
+            z = ctx1.overlaps(db)
+            assert "dual" in ctx1.stats()["kernel_name"]
+        z_big = np.array([[R.mps_inner(x.tensors, y.tensors) for x in big] for y in big])
+        assert np.abs(z - z_big).max() < TOL
