@@ -72,6 +72,14 @@ typedef struct qk_stats {
   int32_t max_bond;    /* largest padded bond among the two sets                      */
   int32_t kernel;      /* which sweep kernel ran: QK_KERNEL_* (see qk_kernel_name)    */
   int32_t precision;   /* 64 or 32: bits of a real of the sets it ran on              */
+  /* A split sweep (sets of very different entanglement: the pairs whose sites all fit the site-fused kernel's smaller LDS
+   * buffer are listed last and swept by its two-workgroups-per-CU shape, right after the launch named by `kernel`):
+   * the second launch's share of the numbers above; all zero when the sweep was one launch. */
+  int64_t second_pairs;
+  double second_flops, second_padded_flops, second_bytes;
+  double second_ms;     /* device time of the second launch (kernel_ms covers both)    */
+  int32_t second_kernel; /* QK_KERNEL_FUSED2, or QK_KERNEL_NONE                          */
+  int32_t reserved;
 } qk_stats;
 
 /* sweep kernels of qk_gram_values (qk_stats.kernel) */
@@ -168,6 +176,10 @@ int64_t qk_plan_total_pairs(const qk_plan* plan);     /* all ranks              
 int64_t qk_plan_max_pairs_per_rank(const qk_plan* plan);
 const int32_t* qk_plan_pairs(const qk_plan* plan);    /* [num_pairs][2] = (i, j), host  */
 int qk_plan_stats(const qk_plan* plan, qk_stats* out); /* algorithmic flops/bytes of this rank's share */
+/* Pairs [qk_plan_first_run, num_pairs) are the pairs with >= QK_PLAN_SPLIT (environment, default 0.75) of their padded work in
+ * sites that fit the site-fused kernel's smaller LDS buffer; qk_gram_values sweeps the two runs with the kernel's two shapes
+ * (one launch each).  == num_pairs when the plan holds (nearly) one class only.                                          */
+int64_t qk_plan_first_run(const qk_plan* plan);
 
 /* ---- the hot path -----------------------------------------------------------
  * qk_gram_values: for every pair p of the plan compute z_p = <x_i|y_j> and write

@@ -25,7 +25,8 @@ struct qk_ctx {
   int num_cus = 0;
   hipStream_t own_stream = nullptr;
   hipStream_t stream = nullptr;
-  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  bool split_pending = false;  // the last sweep was two launches: second_ms is still to be read from the events
+  hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_mid = nullptr;  // ev_mid: between the two launches of a split sweep
   bool ev_pending = false;
   double* scratch = nullptr;
   size_t scratch_bytes = 0;
@@ -38,6 +39,7 @@ struct qk_ctx {
   bool wave2_ring = true;  // ... with its k-step groups prefetched through a per-wave LDS ring (QK_WAVE2=2: plain loads)
   bool wave2_path = true;  // fp64 sets whose bonds are all <= 32 use the one-wave-per-pair sweep with 2 x 2 register tiles (QK_WAVE2=0 opts out)
   bool small_path = true;  // sets whose bonds are all <= 32 use the LDS-resident small-bond sweep (QK_SMALL=0 opts out)
+  bool fused_split = true;  // sweep the plan's two runs of pairs with the two shapes of the site-fused kernel (QK_FUSED_SPLIT=0: one shape)
   int fused_wgs = 0;       // workgroups per CU of the site-fused sweep: 0 = chosen per launch from the plan, 1 / 2 forced (QK_FUSED_WGS)
   int fused_path = 1;      // fp64 sets with a bond > 32 use the site-fused sweep (QK_FUSED=0: ring sweep instead; 2: also for bonds 17..32)
   qk_stats last{};
@@ -66,6 +68,8 @@ struct qk_plan {
   std::vector<int32_t> groups;  // (first pair, count): runs of <= group pairs that share the x state
   int group = 1;
   qk_stats stats{};
+  qk_stats second{};       // pairs / flops / padded_flops / bytes of the class-1 run [n_first, end)
+  int64_t n_first = 0;     // pairs [n_first, end) are the class whose sites fit the fused sweep's smaller LDS buffer (== number of pairs: no split)
   double big_share = 0.0;  // share of this rank's padded work in sites whose X or X' does not fit the fused sweep's larger LDS buffer
   double fit_two = 1.0;  // share of this rank's padded work in sites whose X and X' fit the fused sweep's smaller LDS buffer
   // lazily uploaded copy

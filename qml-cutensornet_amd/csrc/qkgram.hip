@@ -177,6 +177,7 @@ extern "C" int qk_plan_create(int32_t n_sites, int32_t nx, const int32_t* x_dims
     int32_t i, j;
     float cost;
     int32_t tile = 0;
+    int32_t cls = 0;  // 1: nearly all of the pair's work sits in sites that fit the fused sweep's smaller LDS buffer
   };
   if (flags & QK_PLAN_QUADS) {
     // 2x2 blocks of pairs {i1, i2} x {j1, j2} (duos of consecutive states; the last duo of an odd set names its state
@@ -229,6 +230,7 @@ extern "C" int qk_plan_create(int32_t n_sites, int32_t nx, const int32_t* x_dims
       ++t;
     }
     p->groups = {0, 0};
+    p->n_first = (int64_t)p->pairs.size() / 2;
     p->total_pairs = 4 * t;
     p->max_per_rank = *std::max_element(per_rank.begin(), per_rank.end());
     p->stats.pairs = (int64_t)p->pairs.size() / 2;
@@ -286,30 +288,49 @@ extern "C" int qk_plan_create(int32_t n_sites, int32_t nx, const int32_t* x_dims
     p->group = G;
     const int64_t np = (int64_t)p->pairs.size() / 2;
     std::vector<Item> mine((size_t)np);
+    // Two classes of pairs: a set of states of very different entanglement (the 60-qubit x 6-layer set: largest bond 40 ... 248,
+    // median 78) holds pairs that are best swept by one 12-wave workgroup per CU next to pairs whose sites all fit the
+    // smaller LDS buffer and are best swept two workgroups per CU.  Class-1 pairs (>= QK_PLAN_SPLIT, default 0.75, of their
+    // padded work fits the smaller buffer) are listed behind the others; qk_gram_values may sweep the two runs with the two
+    // shapes of the site-fused kernel.
+    double split = 0.75;
+    if (const char* e = std::getenv("QK_PLAN_SPLIT")) split = std::atof(e);
+    double small_work = 0;
     for (int64_t q = 0; q < np; ++q) {
-      double f, fp, by;
+      double f, fp, by, ft;
       const int i = p->pairs[2 * q], j = p->pairs[2 * q + 1];
-      pair_work(n_sites, x_dims + (int64_t)i * stride, y_dims + (int64_t)j * stride, &f, &fp, &by);
-      mine[(size_t)q] = {i, j, (float)fp, tile_of[(size_t)q]};
+      pair_work(n_sites, x_dims + (int64_t)i * stride, y_dims + (int64_t)j * stride, &f, &fp, &by, &ft);
+      const int cls = (fp > 0 && ft >= split * fp) ? 1 : 0;
+      if (cls) small_work += fp, p->second.pairs += 1, p->second.flops += f, p->second.padded_flops += fp, p->second.bytes += by;
+      mine[(size_t)q] = {i, j, (float)fp, tile_of[(size_t)q], cls};
     }
-    std::stable_sort(mine.begin(), mine.end(), [](const Item& u, const Item& v) { return u.tile != v.tile ? u.tile < v.tile : u.i != v.i ? u.i < v.i : u.cost > v.cost; });
+    if (small_work < 0.05 * padded || small_work > 0.95 * padded) {  // (nearly) one class: no split
+      for (Item& it : mine) it.cls = 0;
+      p->second = qk_stats{};
+    }
+    std::stable_sort(mine.begin(), mine.end(), [](const Item& u, const Item& v) {
+      return u.cls != v.cls ? u.cls < v.cls : u.tile != v.tile ? u.tile < v.tile : u.i != v.i ? u.i < v.i : u.cost > v.cost;
+    });
     struct Grp {
       int64_t start;
       int count;
       double cost;
-      int32_t tile;
+      int32_t tile, cls;
     };
     std::vector<Grp> grp;
     for (int64_t q = 0; q < np;) {
       int c = 1;
       double cost = mine[(size_t)q].cost;
-      while (c < G && q + c < np && mine[(size_t)(q + c)].i == mine[(size_t)q].i && mine[(size_t)(q + c)].tile == mine[(size_t)q].tile) cost += mine[(size_t)(q + c)].cost, ++c;
-      grp.push_back({q, c, cost, mine[(size_t)q].tile});
+      while (c < G && q + c < np && mine[(size_t)(q + c)].i == mine[(size_t)q].i && mine[(size_t)(q + c)].tile == mine[(size_t)q].tile && mine[(size_t)(q + c)].cls == mine[(size_t)q].cls)
+        cost += mine[(size_t)(q + c)].cost, ++c;
+      grp.push_back({q, c, cost, mine[(size_t)q].tile, mine[(size_t)q].cls});
       q += c;
     }
-    std::stable_sort(grp.begin(), grp.end(), [](const Grp& u, const Grp& v) { return u.tile != v.tile ? u.tile < v.tile : u.cost > v.cost; });
+    std::stable_sort(grp.begin(), grp.end(), [](const Grp& u, const Grp& v) { return u.cls != v.cls ? u.cls < v.cls : u.tile != v.tile ? u.tile < v.tile : u.cost > v.cost; });
     p->pairs.clear();
+    p->n_first = np;
     for (const Grp& gq : grp) {
+      if (gq.cls == 1 && p->n_first == np) p->n_first = (int64_t)p->pairs.size() / 2;  // where the class-1 run starts
       p->groups.push_back((int32_t)(p->pairs.size() / 2));
       p->groups.push_back(gq.count);
       for (int c = 0; c < gq.count; ++c) {
@@ -339,6 +360,7 @@ extern "C" int64_t qk_plan_num_pairs(const qk_plan* p) { return p ? (int64_t)p->
 extern "C" int64_t qk_plan_total_pairs(const qk_plan* p) { return p ? p->total_pairs : 0; }
 extern "C" int64_t qk_plan_max_pairs_per_rank(const qk_plan* p) { return p ? p->max_per_rank : 0; }
 extern "C" const int32_t* qk_plan_pairs(const qk_plan* p) { return p ? p->pairs.data() : nullptr; }
+extern "C" int64_t qk_plan_first_run(const qk_plan* p) { return p ? (p->n_first > 0 ? p->n_first : (int64_t)p->pairs.size() / 2) : 0; }
 extern "C" int qk_plan_stats(const qk_plan* p, qk_stats* out) {
   if (!p || !out) return fail(QK_EINVAL, "qk_plan_stats: null argument");
   *out = p->stats;
@@ -420,7 +442,8 @@ static int ctx_init(qk_ctx* c, int device_id, int num_cus) {
   c->stream = c->own_stream;
   HIP_TRY(hipEventCreate(&c->ev0));
   HIP_TRY(hipEventCreate(&c->ev1));
-  HIP_TRY(hipMalloc(&c->counter, sizeof(unsigned long long)));
+  HIP_TRY(hipEventCreate(&c->ev_mid));
+  HIP_TRY(hipMalloc(&c->counter, 2 * sizeof(unsigned long long)));  // one work queue per launch of a split sweep
   HIP_TRY(hipMalloc(&c->prof, 8 * sizeof(unsigned long long)));
   HIP_TRY(hipMemset(c->prof, 0, 8 * sizeof(unsigned long long)));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(qk_sweep_ring_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
@@ -441,6 +464,7 @@ static int ctx_init(qk_ctx* c, int device_id, int num_cus) {
   if (const char* v = std::getenv("QK_WAVE")) c->wave_path = std::atoi(v) != 0;
   if (const char* v = std::getenv("QK_WAVE2")) c->wave2_path = std::atoi(v) != 0, c->wave2_ring = std::atoi(v) != 2;
   if (const char* v = std::getenv("QK_FUSED")) c->fused_path = std::atoi(v);
+  if (const char* v = std::getenv("QK_FUSED_SPLIT")) c->fused_split = std::atoi(v) != 0;
   if (const char* v = std::getenv("QK_FUSED_WGS")) c->fused_wgs = std::max(0, std::min(2, std::atoi(v)));
   if (const char* v = std::getenv("QK_WGS_PER_CU")) c->wgs_per_cu = std::max(1, std::min(4, std::atoi(v)));
   return QK_OK;
@@ -455,6 +479,7 @@ extern "C" int qk_ctx_destroy(qk_ctx* c) {
   if (c->prof) (void)hipFree(c->prof);
   if (c->ev0) (void)hipEventDestroy(c->ev0);
   if (c->ev1) (void)hipEventDestroy(c->ev1);
+  if (c->ev_mid) (void)hipEventDestroy(c->ev_mid);
   if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
   delete c;
   return QK_OK;
@@ -706,6 +731,7 @@ extern "C" int qk_gram_values(qk_ctx* c, const qk_mps_set* xs, const qk_mps_set*
   HIP_TRY(hipSetDevice(c->device));
   const long long np = (long long)plan->pairs.size() / 2;
   c->last = plan->stats;
+  c->split_pending = false;
   c->last.max_bond = std::max(xs->max_pad, ys->max_pad);
   c->last.kernel_ms = 0;
   c->last.grid = 0;
@@ -741,7 +767,11 @@ extern "C" int qk_gram_values(qk_ctx* c, const qk_mps_set* xs, const qk_mps_set*
   const bool fused_two = fused && can_two && (!can_one || c->fused_wgs == 2 || (c->fused_wgs == 0 && plan->fit_two >= 0.75));
   const size_t lds_fused = (size_t)(fused_two ? QKF_XCAP_TWO : QKF_XCAP_ONE) * 16 + lds_meta;
   const int grid = (int)std::min<long long>(units, (long long)(fused ? (fused_two ? 2 : 1) : c->wgs_per_cu) * c->num_cus);
-  const size_t need = (size_t)grid * (size_t)chains * 2 * (size_t)(x_plane + t_plane) * sizeof(double);
+  const char* dual_env = std::getenv("QK_FUSED_DUAL");
+  const bool dual = fused && !fused_two && (dual_env ? std::atoi(dual_env) != 0 : plan->big_share >= 0.5);
+  // two runs of pairs, two shapes (see qk_plan_create): only when the launch is free to choose its shape
+  const bool split = fused && !fused_two && !dual && can_two && c->fused_wgs == 0 && c->fused_split && plan->n_first > 0 && plan->n_first < np;
+  const size_t need = (size_t)(split ? 2 * c->num_cus : grid) * (size_t)chains * 2 * (size_t)(x_plane + t_plane) * sizeof(double);
   if (need > c->scratch_bytes) {
     HIP_TRY(hipStreamSynchronize(c->stream));
     if (c->scratch) HIP_TRY(hipFree(c->scratch));
@@ -764,7 +794,7 @@ extern "C" int qk_gram_values(qk_ctx* c, const qk_mps_set* xs, const qk_mps_set*
   if (const char* v = std::getenv("QK_DEBUG_FLAGS")) a.debug_flags = std::atoi(v);
   if (const char* v = std::getenv("QK_PRIO")) a.prio_mode = std::atoi(v);
 #endif
-  HIP_TRY(hipMemsetAsync(c->counter, 0, sizeof(unsigned long long), c->stream));
+  HIP_TRY(hipMemsetAsync(c->counter, 0, 2 * sizeof(unsigned long long), c->stream));
   HIP_TRY(hipEventRecord(c->ev0, c->stream));
   int launched_grid = grid;
   // per-pair site metadata in LDS behind the three ring slots: 4 (n+1) ints + 2 n int64 (+ alignment)
@@ -814,11 +844,23 @@ extern "C" int qk_gram_values(qk_ctx* c, const qk_mps_set* xs, const qk_mps_set*
     HIP_TRY(hipEventRecord(c->ev0, c->stream));        // the conversion above is not part of the sweep
     // the dual form (pairs of tiles per wave) pays on sites that run in strips -- uniform bonds 128 / 192 / 256: +8 / +5 / +15 % --
     // and costs on the small ones (bonds 48: -9 %; the 60-qubit x 6-layer headline set, 11 % of its work in strip sites: -14 %)
-    const char* dual_env = std::getenv("QK_FUSED_DUAL");
-    const bool dual = !fused_two && (dual_env ? std::atoi(dual_env) != 0 : plan->big_share >= 0.5);
     if (fused_two) QKF_KERNEL_TWO<<<dim3(grid), dim3(64 * QKF_TWO_NW), lds_fused, c->stream>>>(a);
     else if (dual) QKF_KERNEL_DUAL<<<dim3(grid), dim3(64 * QKF_DUAL_NW), lds_fused, c->stream>>>(a);
-    else QKF_KERNEL_ONE<<<dim3(grid), dim3(64 * QKF_ONE_NW), lds_fused, c->stream>>>(a);
+    else if (split) {
+      // the plan lists the pairs whose sites fit the smaller LDS buffer behind the others: one 12-wave workgroup per CU for
+      // the first run, two 8-wave workgroups per CU for the second, back to back on the stream
+      SweepArgs a1 = a, a2 = a;
+      a1.npairs = plan->n_first;
+      a2.pairs = a.pairs + 2 * plan->n_first, a2.npairs = np - plan->n_first;
+      a2.values = a.values + plan->n_first, a2.z = a.z ? a.z + 2 * plan->n_first : nullptr;
+      a2.counter = c->counter + 1;
+      QKF_KERNEL_ONE<<<dim3((unsigned)std::min<long long>(a1.npairs, c->num_cus)), dim3(64 * QKF_ONE_NW), lds_fused, c->stream>>>(a1);
+      HIP_TRY(hipEventRecord(c->ev_mid, c->stream));
+      QKF_KERNEL_TWO<<<dim3((unsigned)std::min<long long>(a2.npairs, 2ll * c->num_cus)), dim3(64 * QKF_TWO_NW), (size_t)QKF_XCAP_TWO * 16 + lds_meta, c->stream>>>(a2);
+      c->last.second_pairs = plan->second.pairs, c->last.second_flops = plan->second.flops, c->last.second_padded_flops = plan->second.padded_flops;
+      c->last.second_bytes = plan->second.bytes, c->last.second_kernel = QK_KERNEL_FUSED2;
+      c->split_pending = true;
+    } else QKF_KERNEL_ONE<<<dim3(grid), dim3(64 * QKF_ONE_NW), lds_fused, c->stream>>>(a);
     c->last.kernel = fused_two ? QK_KERNEL_FUSED2 : dual ? QK_KERNEL_FUSED_DUAL : QK_KERNEL_FUSED1;
   } else if (f32) {  // complex64 sweep: the ring kernel on fp32 planes; QK_VARIANT does not apply
     qk_sweep_ring_kernel<float><<<dim3(grid), dim3(512), lds_ring, c->stream>>>(a);
@@ -895,6 +937,11 @@ extern "C" int qk_get_stats(qk_ctx* c, qk_stats* out) {
     float ms = 0;
     HIP_TRY(hipEventElapsedTime(&ms, c->ev0, c->ev1));
     c->last.kernel_ms = ms;
+    if (c->split_pending) {
+      HIP_TRY(hipEventElapsedTime(&ms, c->ev_mid, c->ev1));
+      c->last.second_ms = ms;
+      c->split_pending = false;
+    }
     c->ev_pending = false;
   }
   *out = c->last;

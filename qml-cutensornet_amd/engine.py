@@ -36,6 +36,13 @@ class QkStats(C.Structure):
         ("max_bond", C.c_int32),
         ("kernel", C.c_int32),
         ("precision", C.c_int32),
+        ("second_pairs", C.c_int64),
+        ("second_flops", C.c_double),
+        ("second_padded_flops", C.c_double),
+        ("second_bytes", C.c_double),
+        ("second_ms", C.c_double),
+        ("second_kernel", C.c_int32),
+        ("reserved", C.c_int32),
     ]
 
     def as_dict(self):
@@ -71,6 +78,7 @@ _SIGNATURES = [
     ("qk_plan_max_pairs_per_rank", C.c_int64, [_P]),
     ("qk_plan_pairs", _P, [_P]),
     ("qk_plan_stats", C.c_int, [_P, C.POINTER(QkStats)]),
+    ("qk_plan_first_run", C.c_int64, [_P]),
     ("qk_gram_values", C.c_int, [_P, _P, _P, _P, _P, _P]),
     ("qk_gram_values_host", C.c_int, [_P, _P, _P, _P, _P, _P]),
     ("qk_scatter", C.c_int, [_P, _P, _P, C.c_int64, _P, C.c_int64, C.c_int32]),
@@ -220,6 +228,11 @@ class Plan:
         ptr = lib().qk_plan_pairs(self._h)
         buf = (C.c_int32 * (2 * n)).from_address(ptr)
         return np.frombuffer(buf, dtype=np.int32).reshape(n, 2).copy()
+
+    @property
+    def first_run(self) -> int:
+        """Pairs [first_run, num_pairs) are the run the site-fused sweep takes with its two-workgroups-per-CU shape."""
+        return int(lib().qk_plan_first_run(self._h))
 
     def stats(self) -> dict:
         st = QkStats()
@@ -541,6 +554,7 @@ class Context:
         _check(lib().qk_get_stats(self._h, C.byref(st)), "qk_get_stats")
         d = st.as_dict()
         d["kernel_name"] = lib().qk_kernel_name(st.kernel, st.precision).decode()
+        d["second_kernel_name"] = lib().qk_kernel_name(st.second_kernel, st.precision).decode() if st.second_kernel else ""
         return d
 
     def close(self):

@@ -623,3 +623,27 @@ def test_dual_form_of_the_fused_sweep(gpu_ctx, n, chi_max, nx, ny, seed, monkeyp
             assert "dual" in ctx1.stats()["kernel_name"]
         z_big = np.array([[R.mps_inner(x.tensors, y.tensors) for x in big] for y in big])
         assert np.abs(z - z_big).max() < TOL
+
+
+def test_split_sweep_two_shapes_one_gram(gpu_ctx, monkeypatch):
+    """A set of small and large states: the plan's second run (pairs whose sites fit the smaller LDS buffer) is swept by the
+    two-workgroups-per-CU shape right after the first; same values as the one-shape sweep and as the oracle."""
+    import qml_cutensornet_amd as Q
+    from qml_cutensornet_amd import engine
+    from oracle import restatement as R
+
+    rng = np.random.default_rng(31)
+    n = 16
+    caps = [40, 48, 56, 60, 150, 120, 100, 64]
+    xs = [Q.random_mps(n, [min(2 ** min(k, n - k), c) for k in range(n + 1)], rng) for c in caps]
+    K_ref = np.array([[abs(R.mps_inner(x.tensors, y.tensors)) ** 2 for x in xs] for y in xs])
+    with gpu_ctx.upload(xs) as dx:
+        K = gpu_ctx.gram(dx)
+        st = gpu_ctx.stats()
+        assert st["kernel_name"].startswith("qk_sweep_fused_kernel<12") and st["second_kernel_name"].startswith("qk_sweep_fused_kernel<8")
+        assert 0 < st["second_pairs"] < st["pairs"] and 0 < st["second_ms"] < st["kernel_ms"] and 0 < st["second_flops"] < st["flops"]
+    monkeypatch.setenv("QK_FUSED_SPLIT", "0")
+    with engine.context(0) as ctx1, ctx1.upload(xs) as dx1:
+        K1 = ctx1.gram(dx1)
+        assert ctx1.stats()["second_kernel"] == 0 and ctx1.stats()["second_ms"] == 0
+    assert np.abs(K - K_ref).max() < TOL and np.abs(K - K1).max() < 1e-13 and np.array_equal(K, K.T)
