@@ -672,17 +672,20 @@ __global__ __launch_bounds__(64 * NW, WPS) void qk_sweep_fused_dual_kernel(const
   }
 }
 
-// split planes (re | im) of a set image -> interleaved complex128, same offsets; one workgroup per (state, site)
-__global__ void qk_interleave_kernel(const double* __restrict__ src, double* __restrict__ dst, const int32_t* __restrict__ dims, const int64_t* __restrict__ offs,
+// split planes (re | im) of a set image -> interleaved complex (complex128 for double, complex64 for float), same offsets;
+// one workgroup per (state, site)
+template <typename T>
+__global__ void qk_interleave_kernel(const T* __restrict__ src, T* __restrict__ dst, const int32_t* __restrict__ dims, const int64_t* __restrict__ offs,
                                      const int n_sites, const long long n_tensors) {
+  typedef T v2 __attribute__((ext_vector_type(2)));
   for (long long t = blockIdx.x; t < n_tensors; t += gridDim.x) {
     const long long s = t / n_sites;
     const int k = (int)(t - s * n_sites);
     const long long plane = (long long)dims[s * (n_sites + 1) + k] * 2 * dims[s * (n_sites + 1) + k + 1];
-    const double* re = src + offs[t];
-    const double* im = re + plane;
-    v2d* d = reinterpret_cast<v2d*>(dst + offs[t]);
-    for (long long e = threadIdx.x; e < plane; e += blockDim.x) d[e] = (v2d){re[e], im[e]};
+    const T* re = src + offs[t];
+    const T* im = re + plane;
+    v2* d = reinterpret_cast<v2*>(dst + offs[t]);
+    for (long long e = threadIdx.x; e < plane; e += blockDim.x) d[e] = (v2){re[e], im[e]};
   }
 }
 
@@ -710,16 +713,25 @@ __device__ __forceinline__ void qkw_wait_vmcnt() {
 // NG > 0: the k-step groups (4 fragments of 1 KiB) reach the wave through a private LDS ring of NG groups filled by LDS-DMA,
 // NG - 1 .. NG groups ahead of the matrix instructions (the fetch side walks the same loop nest as a small scalar state
 // machine, across site boundaries).  NG = 0: plain loads into registers right before use (4 KiB in flight per wave).
-template <int NG>
+// SRC = float: the set image is complex64 (interleaved), the arithmetic stays fp64 -- the sweep is bound by the bytes it
+// streams, so single-precision STORAGE halves its time while the only error left is the rounding of the inputs.  A group
+// is then 16 rows x 16 columns x 8 bytes = 2 KiB, fetched as one or two 1-KiB pieces (8 rows each, 16 bytes per lane).
+template <int NG, typename SRC>
 __global__ __launch_bounds__(64, 2) void qk_sweep_wave2_kernel(const SweepArgs g) {
+  constexpr bool F32 = sizeof(SRC) == 4;
+  static_assert(!F32 || NG > 0, "complex64 images go through the LDS ring");
+  constexpr int ES = F32 ? 8 : 16;  // bytes of a complex element of the image (addresses below are byte addresses: pointers to a
+                                    // vector of the template's scalar make hipcc drop the host-side stub of the kernel without a word)
+  constexpr int GROUP = F32 ? 128 : 256;  // v2d-sized (16-byte) units of LDS per group
   __shared__ long long slot;
-  __shared__ v2d ring[NG > 0 ? NG * 4 * 64 : 1];
+  __shared__ v2d ring[NG > 0 ? NG * GROUP : 1];
   typedef __attribute__((address_space(3))) void* lds_ptr_t;
   const int lane = threadIdx.x, j = lane & 15, q = lane >> 4;
-  const unsigned ring_lds = (unsigned)(uintptr_t)(lds_ptr_t)ring + (unsigned)lane * 16u;  // this lane's byte address in slot 0, fragment 0
+  // this lane's byte address in slot 0: fragment 0 (k-step 0) of the group
+  const unsigned ring_lds = (unsigned)(uintptr_t)(lds_ptr_t)ring + (F32 ? (unsigned)(q * 128 + j * 8) : (unsigned)lane * 16u);
   const int ns = g.n_sites, n1 = ns + 1;
-  const v2d* const xdata = reinterpret_cast<const v2d*>(g.xdata);
-  const v2d* const ydata = reinterpret_cast<const v2d*>(g.ydata);
+  const char* const xdata = reinterpret_cast<const char*>(g.xdata);
+  const char* const ydata = reinterpret_cast<const char*>(g.ydata);
   auto uni = [](const int v) __attribute__((always_inline)) { return __builtin_amdgcn_readfirstlane(v); };
   auto unil = [](const long long v) __attribute__((always_inline)) {
     const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v);
@@ -752,8 +764,8 @@ __global__ __launch_bounds__(64, 2) void qk_sweep_wave2_kernel(const SweepArgs g
     // ---- fetch side (NG > 0): group order = for tb, ta, p: { P1 groups tk < kb, P2 groups tn < nn }, site after site
     int f_k = 0, f_tb = 0, f_ta = 0, f_p = 0, f_h = 0, f_slot = 0, c_slot = 0, f_ahead = 0;
     int f_a = xd[0], f_a2 = xd[1], f_b = yd[0], f_b2 = yd[1], f_at = xt[0], f_bt = yt[0];
-    const v2d* f_A = xdata + (xo[0] >> 1);
-    const v2d* f_B = ydata + (yo[0] >> 1);
+    const char* f_A = xdata + (xo[0] >> 1) * ES;
+    const char* f_B = ydata + (yo[0] >> 1) * ES;
     // fetch the next group: only its k-steps below the true bond (the rows above are zero padding; they make up a third
     // of the image at bonds around 20).  Returns the number of fragments it asked for.
     auto issue = [&]() __attribute__((always_inline)) {
@@ -762,11 +774,22 @@ __global__ __launch_bounds__(64, 2) void qk_sweep_wave2_kernel(const SweepArgs g
       const bool is_b = f_h < kb;
       const int ld = is_b ? f_b2 : f_a2;
       const int cnt = is_b ? min(4, (f_bt - f_h * TILE + 3) >> 2) : min(4, (f_at - f_ta * TILE + 3) >> 2);
-      const v2d* const base = is_b ? f_B + ((f_h * TILE) * 2 + f_p) * f_b2 + f_tb * TILE : f_A + ((f_ta * TILE) * 2 + f_p) * f_a2 + (f_h - kb) * TILE;
-      const v2d* const src = base + (q * 2) * ld + j;
+      const char* const base = is_b ? f_B + (((f_h * TILE) * 2 + f_p) * f_b2 + f_tb * TILE) * ES : f_A + (((f_ta * TILE) * 2 + f_p) * f_a2 + (f_h - kb) * TILE) * ES;
+      int asked;
+      if constexpr (F32) {
+        // piece d = rows 8 d .. 8 d + 7 (two k-steps): lane L brings the 16 bytes of columns 2 (L & 7), + 1 of row 8 d + (L >> 3)
+        const char* const src = base + (((lane >> 3) * 2) * ld + (lane & 7) * 2) * ES;
+        asked = (cnt + 1) >> 1;
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
-        if (i < cnt) __builtin_amdgcn_global_load_lds(src + i * 8 * ld, (lds_ptr_t)(ring + (f_slot * 4 + i) * 64), 16, 0, 0);
+        for (int d = 0; d < 2; ++d)
+          if (d < asked) __builtin_amdgcn_global_load_lds(src + (d * 16 * ld) * ES, (lds_ptr_t)(ring + f_slot * GROUP + d * 64), 16, 0, 0);
+      } else {
+        const char* const src = base + ((q * 2) * ld + j) * ES;
+        asked = cnt;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          if (i < cnt) __builtin_amdgcn_global_load_lds(src + (i * 8 * ld) * ES, (lds_ptr_t)(ring + (f_slot * 4 + i) * 64), 16, 0, 0);
+      }
       f_slot = (f_slot == NG - 1) ? 0 : f_slot + 1;
       if (++f_h == kb + nn) {
         f_h = 0;
@@ -778,13 +801,13 @@ __global__ __launch_bounds__(64, 2) void qk_sweep_wave2_kernel(const SweepArgs g
               f_tb = 0;
               if (++f_k < ns) {
                 f_a = f_a2, f_b = f_b2, f_a2 = xd[f_k + 1], f_b2 = yd[f_k + 1], f_at = xt[f_k], f_bt = yt[f_k];
-                f_A = xdata + (xo[f_k] >> 1), f_B = ydata + (yo[f_k] >> 1);
+                f_A = xdata + (xo[f_k] >> 1) * ES, f_B = ydata + (yo[f_k] >> 1) * ES;
               }
             }
           }
         }
       }
-      return cnt;
+      return asked;
     };
     // the next group of the order above, as four fragments in registers (those above the true bond hold stale data and
     // are not used).  f_ahead = fragments asked for behind the group that is taken.
@@ -803,12 +826,26 @@ __global__ __launch_bounds__(64, 2) void qk_sweep_wave2_kernel(const SweepArgs g
       }
       f_ahead = more;
       // (read by hand: the compiler puts vmcnt(0) in front of every LDS read it can see next to an LDS-DMA)
-      const unsigned at = ring_lds + (unsigned)c_slot * 4096u;
-      asm volatile("ds_read_b128 %0, %1" : "=v"(f[0]) : "v"(at));
-      asm volatile("ds_read_b128 %0, %1 offset:1024" : "=v"(f[1]) : "v"(at));
-      asm volatile("ds_read_b128 %0, %1 offset:2048" : "=v"(f[2]) : "v"(at));
-      asm volatile("ds_read_b128 %0, %1 offset:3072" : "=v"(f[3]) : "v"(at));
-      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3])::"memory");
+      const unsigned at = ring_lds + (unsigned)c_slot * (unsigned)(GROUP * 16);
+      if constexpr (F32) {  // k-step i of lane (q, j): row q + 4 i, column j of the 16 x 16 image (128-byte rows)
+        double h[4];  // (two floats each)
+        asm volatile("ds_read_b64 %0, %1" : "=v"(h[0]) : "v"(at));
+        asm volatile("ds_read_b64 %0, %1 offset:512" : "=v"(h[1]) : "v"(at));
+        asm volatile("ds_read_b64 %0, %1 offset:1024" : "=v"(h[2]) : "v"(at));
+        asm volatile("ds_read_b64 %0, %1 offset:1536" : "=v"(h[3]) : "v"(at));
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(h[0]), "+v"(h[1]), "+v"(h[2]), "+v"(h[3])::"memory");
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const long long bits = __double_as_longlong(h[i]);
+          f[i] = (v2d){(double)__int_as_float((int)bits), (double)__int_as_float((int)(bits >> 32))};
+        }
+      } else {
+        asm volatile("ds_read_b128 %0, %1" : "=v"(f[0]) : "v"(at));
+        asm volatile("ds_read_b128 %0, %1 offset:1024" : "=v"(f[1]) : "v"(at));
+        asm volatile("ds_read_b128 %0, %1 offset:2048" : "=v"(f[2]) : "v"(at));
+        asm volatile("ds_read_b128 %0, %1 offset:3072" : "=v"(f[3]) : "v"(at));
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3])::"memory");
+      }
       c_slot = (c_slot == NG - 1) ? 0 : c_slot + 1;
     };
     if constexpr (NG > 0) {
@@ -821,8 +858,8 @@ __global__ __launch_bounds__(64, 2) void qk_sweep_wave2_kernel(const SweepArgs g
     long long xo_nx = xo[0], yo_nx = yo[0];
     for (int k = 0; k < ns; ++k) {
       const int a = a_nx, a2 = a2_nx, b = b_nx, b2 = b2_nx, at = at_nx, bt = bt_nx;
-      const v2d* const Ak = xdata + (xo_nx >> 1);
-      const v2d* const Bk = ydata + (yo_nx >> 1);
+      const v2d* const Ak = reinterpret_cast<const v2d*>(xdata) + (xo_nx >> 1);  // (the plain-load path: complex128 images only)
+      const v2d* const Bk = reinterpret_cast<const v2d*>(ydata) + (yo_nx >> 1);
       {
         const int k1 = min(k + 1, ns - 1);
         a_nx = a2, b_nx = b2, a2_nx = xd[k1 + 1], b2_nx = yd[k1 + 1], at_nx = xt[k1], bt_nx = yt[k1];

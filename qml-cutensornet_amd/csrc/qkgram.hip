@@ -694,10 +694,12 @@ extern "C" int qk_mps_set_to_f32(qk_ctx* c, const qk_mps_set* src, qk_mps_set** 
 // the interleaved complex128 image of a set, made once on the device from the split planes
 static int ensure_interleaved(qk_ctx* c, qk_mps_set* m) {
   if (m->d_il) return QK_OK;
-  if (m->precision != 64) return fail(QK_EINVAL, "the site-fused sweep needs an fp64 set");
   HIP_TRY(hipMalloc(&m->d_il, (size_t)m->bytes));
   const long long nt = (long long)m->n_states * m->n_sites;
-  qk_interleave_kernel<<<dim3((unsigned)std::min<long long>(nt, 64ll * c->num_cus)), dim3(256), 0, c->stream>>>(m->d_data, m->d_il, m->d_dims, m->d_offs, m->n_sites, nt);
+  const dim3 grid((unsigned)std::min<long long>(nt, 64ll * c->num_cus));
+  if (m->precision == 64) qk_interleave_kernel<double><<<grid, dim3(256), 0, c->stream>>>(m->d_data, m->d_il, m->d_dims, m->d_offs, m->n_sites, nt);
+  else  // complex64 image of an fp32 set (same offsets, counted in floats)
+    qk_interleave_kernel<float><<<grid, dim3(256), 0, c->stream>>>(reinterpret_cast<const float*>(m->d_data), reinterpret_cast<float*>(m->d_il), m->d_dims, m->d_offs, m->n_sites, nt);
   HIP_TRY(hipGetLastError());
   return QK_OK;
 }
@@ -764,13 +766,14 @@ extern "C" int qk_gram_values(qk_ctx* c, const qk_mps_set* xs, const qk_mps_set*
   const bool can_one = max_pad <= QKF_XCAP_ONE / TILE && (size_t)QKF_XCAP_ONE * 16 + lds_meta <= 160 * 1024;
   const bool can_two = max_pad <= QKF_XCAP_TWO / TILE && (size_t)QKF_XCAP_TWO * 16 + lds_meta <= 80 * 1024;
   const bool fused = fused_ok && (can_one || can_two);
-  const bool fused_two = fused && can_two && (!can_one || c->fused_wgs == 2 || (c->fused_wgs == 0 && plan->fit_two >= 0.75));
+  // two runs of pairs, two shapes (see qk_plan_create): only when the launch is free to choose its shape
+  const bool two_runs = fused && can_one && can_two && c->fused_wgs == 0 && c->fused_split && plan->n_first > 0 && plan->n_first < np;
+  const bool fused_two = fused && can_two && !two_runs && (!can_one || c->fused_wgs == 2 || (c->fused_wgs == 0 && plan->fit_two >= 0.75));
   const size_t lds_fused = (size_t)(fused_two ? QKF_XCAP_TWO : QKF_XCAP_ONE) * 16 + lds_meta;
   const int grid = (int)std::min<long long>(units, (long long)(fused ? (fused_two ? 2 : 1) : c->wgs_per_cu) * c->num_cus);
   const char* dual_env = std::getenv("QK_FUSED_DUAL");
   const bool dual = fused && !fused_two && (dual_env ? std::atoi(dual_env) != 0 : plan->big_share >= 0.5);
-  // two runs of pairs, two shapes (see qk_plan_create): only when the launch is free to choose its shape
-  const bool split = fused && !fused_two && !dual && can_two && c->fused_wgs == 0 && c->fused_split && plan->n_first > 0 && plan->n_first < np;
+  const bool split = two_runs && !dual;
   const size_t need = (size_t)(split ? 2 * c->num_cus : grid) * (size_t)chains * 2 * (size_t)(x_plane + t_plane) * sizeof(double);
   if (need > c->scratch_bytes) {
     HIP_TRY(hipStreamSynchronize(c->stream));
@@ -815,7 +818,7 @@ extern "C" int qk_gram_values(qk_ctx* c, const qk_mps_set* xs, const qk_mps_set*
     const int wgrid = (int)std::min<long long>(np, 16ll * c->num_cus);
     qk_sweep_wave_kernel<0><<<dim3(wgrid), dim3(64), 0, c->stream>>>(a);
     launched_grid = wgrid, c->last.kernel = QK_KERNEL_WAVE;
-  } else if (!fused && c->variant == 20 && c->wave2_path && !f32 && std::max(xs->max_pad, ys->max_pad) <= 32) {
+  } else if (!fused && c->variant == 20 && c->wave2_path && (!f32 || c->wave2_ring) && std::max(xs->max_pad, ys->max_pad) <= 32) {
     // every bond <= 32, fp64: a pair lives in the registers of one wavefront as 2 x 2 tiles (qk_sweep_wave2_kernel); 8 waves per CU
     for (const qk_mps_set* m : {xs, ys}) {
       const int rc_il = ensure_interleaved(c, const_cast<qk_mps_set*>(m));
@@ -824,8 +827,9 @@ extern "C" int qk_gram_values(qk_ctx* c, const qk_mps_set* xs, const qk_mps_set*
     a.xdata = xs->d_il, a.ydata = ys->d_il;
     HIP_TRY(hipEventRecord(c->ev0, c->stream));  // the conversion above is not part of the sweep
     const int wgrid = (int)std::min<long long>(np, 8ll * c->num_cus);
-    if (c->wave2_ring) qk_sweep_wave2_kernel<3><<<dim3(wgrid), dim3(64), 0, c->stream>>>(a);
-    else qk_sweep_wave2_kernel<0><<<dim3(wgrid), dim3(64), 0, c->stream>>>(a);
+    if (f32) qk_sweep_wave2_kernel<3, float><<<dim3(wgrid), dim3(64), 0, c->stream>>>(a);  // complex64 storage, fp64 arithmetic
+    else if (c->wave2_ring) qk_sweep_wave2_kernel<3, double><<<dim3(wgrid), dim3(64), 0, c->stream>>>(a);
+    else qk_sweep_wave2_kernel<0, double><<<dim3(wgrid), dim3(64), 0, c->stream>>>(a);
     launched_grid = wgrid, c->last.kernel = QK_KERNEL_WAVE2;
   } else if (!fused && c->variant == 20 && c->small_path && std::max(xs->max_pad, ys->max_pad) <= 32 && lds_small <= 80 * 1024) {
     // every bond <= 32: X and T stay in LDS, only the site tensors stream (qk_sweep_small_kernel); chains too long for
@@ -918,7 +922,7 @@ extern "C" const char* qk_kernel_name(int32_t kernel, int32_t precision) {
     case QK_KERNEL_FUSED1: return "qk_sweep_fused_kernel<12, 2, 8192, 3>";
     case QK_KERNEL_FUSED2: return "qk_sweep_fused_kernel<8, 1, 4608, 4>";
     case QK_KERNEL_RING: return f32 ? "qk_sweep_ring_kernel<float>" : "qk_sweep_ring_kernel<double>";
-    case QK_KERNEL_WAVE2: return "qk_sweep_wave2_kernel";
+    case QK_KERNEL_WAVE2: return precision == 32 ? "qk_sweep_wave2_kernel<3, float>" : "qk_sweep_wave2_kernel<3, double>";
     case QK_KERNEL_FUSED_DUAL: return "qk_sweep_fused_dual_kernel<12, 8192, 3>";
     case QK_KERNEL_LAB: return "(lab kernel)";
     default: return "(none)";

@@ -390,7 +390,7 @@ def test_small_bond_kernel(gpu_ctx, n, chi_max, nx, ny, seed, monkeypatch):
             z_other = ctx1.overlaps(dx1, dy1)
             seen.add(ctx1.stats()["kernel_name"])
         assert np.abs(z - z_other).max() < 1e-13, env
-    assert {"qk_sweep_wave2_kernel", "qk_sweep_small_kernel<double>", "qk_sweep_ring_kernel<double>"} <= seen
+    assert {"qk_sweep_wave2_kernel<3, double>", "qk_sweep_small_kernel<double>", "qk_sweep_ring_kernel<double>"} <= seen
     assert any("fused" in name_ for name_ in seen) or max(dx.dims.max(), dy.dims.max()) <= 16
 
 
@@ -517,7 +517,7 @@ def test_cfg5_real_states(gpu_ctx, monkeypatch):
     states = _real_states(100, 10, 4, 0.1, 8)
     assert 16 < max(m.max_bond() for m in states) <= 32
     _check_real_workload(gpu_ctx, states, 3)
-    assert gpu_ctx.stats()["kernel_name"] == "qk_sweep_wave2_kernel"
+    assert gpu_ctx.stats()["kernel_name"] == "qk_sweep_wave2_kernel<3, double>"
     for env, name in (({"QK_WAVE2": "0"}, "small"), ({"QK_FUSED": "2"}, "fused"), ({"QK_FUSED": "0", "QK_SMALL": "0"}, "ring")):
         for k_, v_ in env.items():
             monkeypatch.setenv(k_, v_)
@@ -647,3 +647,33 @@ def test_split_sweep_two_shapes_one_gram(gpu_ctx, monkeypatch):
         K1 = ctx1.gram(dx1)
         assert ctx1.stats()["second_kernel"] == 0 and ctx1.stats()["second_ms"] == 0
     assert np.abs(K - K_ref).max() < TOL and np.abs(K - K1).max() < 1e-13 and np.array_equal(K, K.T)
+
+
+def test_complex64_storage_wave_sweep(gpu_ctx, monkeypatch):
+    """Complex64 sets with bonds <= 32 take qk_sweep_wave2_kernel<3, float>: single-precision STORAGE, fp64 arithmetic.  Its
+    result is the fp64 sweep of the rounded tensors -- checked against the oracle ON the rounded tensors to fp64 accuracy --
+    and differs from the exact overlap by the input rounding only (well inside the complex64 tolerance)."""
+    import qml_cutensornet_amd as Q
+    from qml_cutensornet_amd import engine
+    from oracle import restatement as R
+
+    rng = np.random.default_rng(77)
+    for n, chi_max, nx, ny in ((30, 32, 4, 3), (12, 9, 3, 3), (64, 20, 3, 4)):
+        xs = [Q.random_mps(n, _ragged_profile(rng, n, chi_max), rng) for _ in range(nx)]
+        ys = [Q.random_mps(n, _ragged_profile(rng, n, chi_max), rng) for _ in range(ny)]
+        rounded = lambda m: [t.astype(np.complex64).astype(np.complex128) for t in m.tensors]
+        z_exact = np.array([[R.mps_inner(x.tensors, y.tensors) for x in xs] for y in ys])
+        z_round = np.array([[R.mps_inner(rounded(x), rounded(y)) for x in xs] for y in ys])
+        with gpu_ctx.upload(xs) as dx, gpu_ctx.upload(ys) as dy, dx.to_f32() as fx, dy.to_f32() as fy:
+            z32 = gpu_ctx.overlaps(fx, fy)
+            assert gpu_ctx.stats()["kernel_name"] == "qk_sweep_wave2_kernel<3, float>"
+            K32 = gpu_ctx.gram(fx)
+        assert np.abs(z32 - z_round).max() < TOL
+        assert np.abs(z32 - z_exact).max() < F32_TOL
+        assert np.array_equal(K32, K32.T)
+    # QK_WAVE2=0: the complex64 arithmetic path (LDS-resident small-bond sweep) on the same sets
+    monkeypatch.setenv("QK_WAVE2", "0")
+    with engine.context(0) as ctx1, ctx1.upload(xs) as dx, ctx1.upload(ys) as dy, dx.to_f32() as fx, dy.to_f32() as fy:
+        z_small = ctx1.overlaps(fx, fy)
+        assert "small" in ctx1.stats()["kernel_name"]
+    assert np.abs(z_small - z32).max() < F32_TOL
