@@ -761,70 +761,64 @@ __global__ __launch_bounds__(64, 2) void qk_sweep_wave2_kernel(const SweepArgs g
 #pragma unroll
       for (int v = 0; v < 2; ++v) XA[u][v].re = XA[u][v].im = XN[u][v].re = XN[u][v].im = (v4d){0, 0, 0, 0};
     XA[0][0].re[0] = (lane == 0) ? 1.0 : 0.0;  // X_0 = 1: A-operand element [k = 0][m = 0]
-    // ---- fetch side (NG > 0): group order = for tb, ta, p: { P1 groups tk < kb, P2 groups tn < nn }, site after site
-    int f_k = 0, f_tb = 0, f_ta = 0, f_p = 0, f_h = 0, f_slot = 0, c_slot = 0, f_ahead = 0;
-    int f_a = xd[0], f_a2 = xd[1], f_b = yd[0], f_b2 = yd[1], f_at = xt[0], f_bt = yt[0];
-    const char* f_A = xdata + (xo[0] >> 1) * ES;
-    const char* f_B = ydata + (yo[0] >> 1) * ES;
-    // fetch the next group: only its k-steps below the true bond (the rows above are zero padding; they make up a third
-    // of the image at bonds around 20).  Returns the number of fragments it asked for.
+    // ---- fetch side (NG > 0): group order = for tb, ta, p: { P1 groups tk < kb, P2 groups tn < nn }, site after site.
+    // Entering a site, lane g computes the descriptor of the site's group g (<= 32 groups): element offset in its tensor,
+    // k-steps below the true bond, which tensor -- a dozen vector instructions for the whole site; fetching a group is then a
+    // v_readlane and the LDS-DMAs, with no branch but "site finished".  (The first version walked the loop nest as nested
+    // scalar ifs and picked the wait with a switch: ~250 scalar instructions and ~30 branches between two groups of 3-12
+    // MFMAs -- the wave was bound by its own control code.)
+    int f_k = 0, f_i = 0, f_n = 0, f_slot = 0, c_slot = 0;
+    int f_a2 = 0, f_b2 = 0;
+    const char* f_A = xdata;
+    const char* f_B = ydata;
+    int desc = 0;
+    auto enter = [&]() __attribute__((always_inline)) {  // descriptors of site f_k
+      // (pinned to scalar registers: left alone, the compiler folds the two true-bond loads and the per-lane select below into
+      //  ONE per-lane vector load -- and the s_waitcnt vmcnt(0) behind it drains the LDS-DMAs in flight at every site)
+      const int fa = xd[f_k], fb = yd[f_k], fat = __builtin_amdgcn_readfirstlane(xt[f_k]), fbt = __builtin_amdgcn_readfirstlane(yt[f_k]);
+      f_a2 = xd[f_k + 1], f_b2 = yd[f_k + 1];
+      f_A = xdata + (xo[f_k] >> 1) * ES, f_B = ydata + (yo[f_k] >> 1) * ES;
+      const int kb = fb >> 4, nn = f_a2 >> 4, mt = fa >> 4, nt = f_b2 >> 4, gpb = kb + nn;
+      const int inv = (gpb == 2) ? 32768 : (gpb == 3) ? 21846 : 16384;  // g / gpb == (g * inv) >> 16 for g < 64
+      const int gi = lane, blk = (gi * inv) >> 16, h = gi - blk * gpb, pp = blk & 1, r = blk >> 1;
+      const int ta = (mt == 2) ? (r & 1) : 0, tb = (mt == 2) ? (r >> 1) : r;
+      const bool is_b = h < kb;
+      const int off = is_b ? ((h * TILE) * 2 + pp) * f_b2 + tb * TILE : ((ta * TILE) * 2 + pp) * f_a2 + (h - kb) * TILE;
+      const int cnt = is_b ? min(4, (fbt - h * TILE + 3) >> 2) : min(4, (fat - ta * TILE + 3) >> 2);
+      desc = off | (cnt << 16) | ((is_b ? 1 : 0) << 20);
+      f_n = nt * mt * 2 * gpb, f_i = 0;
+    };
+    // fetch the next group: its k-steps below the true bond (the rows above are zero padding: a third of the image at bonds
+    // around 20); the pieces above are asked for again at the address of the last one needed -- an L1 hit, no fabric bytes --
+    // so that every group is the same number of LDS-DMAs and the consumer's wait is a constant.
     auto issue = [&]() __attribute__((always_inline)) {
-      if (f_k >= ns) return 0;
-      const int kb = f_b >> 4, nn = f_a2 >> 4;
-      const bool is_b = f_h < kb;
+      if (f_k >= ns) return;
+      const int d = __builtin_amdgcn_readlane(desc, f_i);
+      const int off = d & 0xffff, cnt = (d >> 16) & 7;
+      const bool is_b = (d >> 20) != 0;
       const int ld = is_b ? f_b2 : f_a2;
-      const int cnt = is_b ? min(4, (f_bt - f_h * TILE + 3) >> 2) : min(4, (f_at - f_ta * TILE + 3) >> 2);
-      const char* const base = is_b ? f_B + (((f_h * TILE) * 2 + f_p) * f_b2 + f_tb * TILE) * ES : f_A + (((f_ta * TILE) * 2 + f_p) * f_a2 + (f_h - kb) * TILE) * ES;
-      int asked;
+      const char* const base = (is_b ? f_B : f_A) + (long)off * ES;
       if constexpr (F32) {
-        // piece d = rows 8 d .. 8 d + 7 (two k-steps): lane L brings the 16 bytes of columns 2 (L & 7), + 1 of row 8 d + (L >> 3)
+        // piece p = rows 8 p .. 8 p + 7 (two k-steps): lane L brings the 16 bytes of columns 2 (L & 7), + 1 of row 8 p + (L >> 3)
         const char* const src = base + (((lane >> 3) * 2) * ld + (lane & 7) * 2) * ES;
-        asked = (cnt + 1) >> 1;
+        const int last = (cnt - 1) >> 1;
 #pragma unroll
-        for (int d = 0; d < 2; ++d)
-          if (d < asked) __builtin_amdgcn_global_load_lds(src + (d * 16 * ld) * ES, (lds_ptr_t)(ring + f_slot * GROUP + d * 64), 16, 0, 0);
+        for (int pc = 0; pc < 2; ++pc) __builtin_amdgcn_global_load_lds(src + (min(pc, last) * 16 * ld) * ES, (lds_ptr_t)(ring + f_slot * GROUP + pc * 64), 16, 0, 0);
       } else {
         const char* const src = base + ((q * 2) * ld + j) * ES;
-        asked = cnt;
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
-          if (i < cnt) __builtin_amdgcn_global_load_lds(src + (i * 8 * ld) * ES, (lds_ptr_t)(ring + (f_slot * 4 + i) * 64), 16, 0, 0);
+        for (int i = 0; i < 4; ++i) __builtin_amdgcn_global_load_lds(src + (min(i, cnt - 1) * 8 * ld) * ES, (lds_ptr_t)(ring + (f_slot * 4 + i) * 64), 16, 0, 0);
       }
       f_slot = (f_slot == NG - 1) ? 0 : f_slot + 1;
-      if (++f_h == kb + nn) {
-        f_h = 0;
-        if (++f_p == 2) {
-          f_p = 0;
-          if (++f_ta == (f_a >> 4)) {
-            f_ta = 0;
-            if (++f_tb == (f_b2 >> 4)) {
-              f_tb = 0;
-              if (++f_k < ns) {
-                f_a = f_a2, f_b = f_b2, f_a2 = xd[f_k + 1], f_b2 = yd[f_k + 1], f_at = xt[f_k], f_bt = yt[f_k];
-                f_A = xdata + (xo[f_k] >> 1) * ES, f_B = ydata + (yo[f_k] >> 1) * ES;
-              }
-            }
-          }
-        }
+      if (++f_i == f_n) {
+        if (++f_k < ns) enter();
       }
-      return asked;
     };
-    // the next group of the order above, as four fragments in registers (those above the true bond hold stale data and
-    // are not used).  f_ahead = fragments asked for behind the group that is taken.
+    // the next group of the order above, as four fragments in registers (those above the true bond hold copies and are not used)
     auto take = [&](v2d(&f)[4]) __attribute__((always_inline)) {
-      const int more = issue();
-      switch (f_ahead + more) {  // <= 4 (NG - 1)
-        case 0: qkw_wait_vmcnt<0>(); break;
-        case 1: qkw_wait_vmcnt<1>(); break;
-        case 2: qkw_wait_vmcnt<2>(); break;
-        case 3: qkw_wait_vmcnt<3>(); break;
-        case 4: qkw_wait_vmcnt<4>(); break;
-        case 5: qkw_wait_vmcnt<5>(); break;
-        case 6: qkw_wait_vmcnt<6>(); break;
-        case 7: qkw_wait_vmcnt<7>(); break;
-        default: qkw_wait_vmcnt<8>(); break;
-      }
-      f_ahead = more;
+      issue();
+      if (f_k >= ns) qkw_wait_vmcnt<0>();  // the last groups of a chain: nothing more is fetched behind them
+      else qkw_wait_vmcnt<(NG > 0 ? (F32 ? 2 : 4) * (NG - 1) : 0)>();
       // (read by hand: the compiler puts vmcnt(0) in front of every LDS read it can see next to an LDS-DMA)
       const unsigned at = ring_lds + (unsigned)c_slot * (unsigned)(GROUP * 16);
       if constexpr (F32) {  // k-step i of lane (q, j): row q + 4 i, column j of the 16 x 16 image (128-byte rows)
@@ -849,9 +843,9 @@ __global__ __launch_bounds__(64, 2) void qk_sweep_wave2_kernel(const SweepArgs g
       c_slot = (c_slot == NG - 1) ? 0 : c_slot + 1;
     };
     if constexpr (NG > 0) {
-      static_assert(NG == 0 || NG == 3, "the wait above counts the two groups behind the one taken");
-      issue();
-      f_ahead = issue();
+      enter();
+#pragma unroll
+      for (int i = 0; i < NG - 1; ++i) issue();
     }
     // the tables of site k + 1 are fetched while site k is swept
     int a_nx = xd[0], b_nx = yd[0], a2_nx = xd[1], b2_nx = yd[1], at_nx = xt[0], bt_nx = yt[0];
