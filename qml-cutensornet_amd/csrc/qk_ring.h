@@ -620,17 +620,27 @@ __global__ __launch_bounds__(64, 4) void qk_sweep_wave_kernel(const SweepArgs g)
     const long long p = uni_ll(slot);  // every per-pair / per-site scalar is made provably wave-uniform: the k-step
     __syncthreads();                   // guards below must be scalar branches around the MFMAs
     if (p >= g.npairs) break;
-    const int xi = uni_i(g.pairs[2 * p]), yj = uni_i(g.pairs[2 * p + 1]);
-    const int* xt = g.xtrue + (long long)xi * n1;
-    const int* yt = g.ytrue + (long long)yj * n1;
-    const int64_t* xo = g.xoffs + (long long)xi * ns;
-    const int64_t* yo = g.yoffs + (long long)yj * ns;
+    // per-pair tables through the scalar cache (wave-uniform addresses in the constant address space), one site ahead: as
+    // vector loads they put a memory latency in front of every site's first tensor load
+    typedef const __attribute__((address_space(4))) int* sint_p;
+    typedef const __attribute__((address_space(4))) int64_t* slong_p;
+    const int xi = ((sint_p)g.pairs)[2 * p], yj = ((sint_p)g.pairs)[2 * p + 1];
+    const sint_p xt = (sint_p)(g.xtrue + (long long)xi * n1);
+    const sint_p yt = (sint_p)(g.ytrue + (long long)yj * n1);
+    const slong_p xo = (slong_p)(g.xoffs + (long long)xi * ns);
+    const slong_p yo = (slong_p)(g.yoffs + (long long)yj * ns);
     // X as A-operand fragments: k-step ks of lane (q, j) = X[4 ks + q][j];  X_0 = 1 at [0][0]
     v4d xr = {(lane == 0) ? 1.0 : 0.0, 0, 0, 0}, xim = {0, 0, 0, 0};
+    int at_nx = xt[0], bt_nx = yt[0];
+    long long xo_nx = xo[0], yo_nx = yo[0];
     for (int k = 0; k < ns; ++k) {
-      const int ksb = (uni_i(yt[k]) + 3) >> 2, ksa = (uni_i(xt[k]) + 3) >> 2;  // k-steps below the true bonds b_k and a_k (1..4)
-      const double* Bre = g.ydata + uni_ll(yo[k]) + foff;  // B_k: [b][2][b'] planes of 512 doubles
-      const double* Are = g.xdata + uni_ll(xo[k]) + foff;  // A_k: [a][2][a']
+      const int ksb = (bt_nx + 3) >> 2, ksa = (at_nx + 3) >> 2;  // k-steps below the true bonds b_k and a_k (1..4)
+      const double* Bre = g.ydata + yo_nx + foff;  // B_k: [b][2][b'] planes of 512 doubles
+      const double* Are = g.xdata + xo_nx + foff;  // A_k: [a][2][a']
+      {
+        const int k1 = min(k + 1, ns - 1);
+        at_nx = xt[k1], bt_nx = yt[k1], xo_nx = xo[k1], yo_nx = yo[k1];
+      }
       // ---- T_p = X^T B_k[:, p, :]
       v4d tr[2], ti[2];
 #pragma unroll
