@@ -830,7 +830,7 @@ extern "C" int qk_gram_values(qk_ctx* c, const qk_mps_set* xs, const qk_mps_set*
     if (f32) qk_sweep_wave2_kernel<3, float><<<dim3(wgrid), dim3(64), 0, c->stream>>>(a);  // complex64 storage, fp64 arithmetic
     else if (c->wave2_ring) qk_sweep_wave2_kernel<3, double><<<dim3(wgrid), dim3(64), 0, c->stream>>>(a);
     else qk_sweep_wave2_kernel<0, double><<<dim3(wgrid), dim3(64), 0, c->stream>>>(a);
-    launched_grid = wgrid, c->last.kernel = QK_KERNEL_WAVE2;
+    launched_grid = wgrid, c->last.kernel = (f32 || c->wave2_ring) ? QK_KERNEL_WAVE2 : QK_KERNEL_WAVE2_PLAIN;
   } else if (!fused && c->variant == 20 && c->small_path && std::max(xs->max_pad, ys->max_pad) <= 32 && lds_small <= 80 * 1024) {
     // every bond <= 32: X and T stay in LDS, only the site tensors stream (qk_sweep_small_kernel); chains too long for
     // its LDS budget (several hundred sites) take the ring kernel below
@@ -923,6 +923,7 @@ extern "C" const char* qk_kernel_name(int32_t kernel, int32_t precision) {
     case QK_KERNEL_FUSED2: return "qk_sweep_fused_kernel<8, 1, 4608, 4>";
     case QK_KERNEL_RING: return f32 ? "qk_sweep_ring_kernel<float>" : "qk_sweep_ring_kernel<double>";
     case QK_KERNEL_WAVE2: return precision == 32 ? "qk_sweep_wave2_kernel<3, float>" : "qk_sweep_wave2_kernel<3, double>";
+    case QK_KERNEL_WAVE2_PLAIN: return "qk_sweep_wave2_kernel<0, double>";
     case QK_KERNEL_FUSED_DUAL: return "qk_sweep_fused_dual_kernel<12, 8192, 3>";
     case QK_KERNEL_LAB: return "(lab kernel)";
     default: return "(none)";
