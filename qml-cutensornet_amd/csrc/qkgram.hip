@@ -105,7 +105,10 @@ extern "C" int qk_pack_state(int32_t n_sites, const int32_t* bond_dims, const do
 // ----------------------------------------------------------------------------------------
 // Algorithmic flops of one overlap: 8 real flops per complex
 // multiply-add, cheaper association per site.  Padded: what this engine executes.
-static constexpr int QKF_XCAP_ONE = 8192, QKF_XCAP_TWO = 4608;  // elements of the fused sweep's LDS X buffer with one / two workgroups per CU
+#ifndef QKF_XCAP_ONE_V
+#define QKF_XCAP_ONE_V 8192
+#endif
+static constexpr int QKF_XCAP_ONE = QKF_XCAP_ONE_V, QKF_XCAP_TWO = 4608;  // elements of the fused sweep's LDS X buffer with one / two workgroups per CU
 // shapes of the two instantiations: waves per workgroup, T slots per wave, waves per SIMD (experiment builds override them)
 #ifndef QKF_ONE_NW
 #define QKF_ONE_NW 12  // three waves per SIMD at 168 VGPRs: 452 against 482 ms for 8 waves x 4 slots on the headline set (16 x 1: 455)
