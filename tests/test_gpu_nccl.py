@@ -88,3 +88,40 @@ def test_four_rank_bench_rehearsal(built, tmp_path):
     ms, work = np.array(d["config"]["rank_kernel_ms"]), np.array(d["config"]["rank_padded_tflop"])
     assert len(ms) == 4 and ms.min() > 0  # (four processes time-share ONE GPU here: their kernel times say nothing about balance)
     assert work.max() / work.min() < 1.01, work  # the serpentine deal of the cost-ordered pairs: equal shares of the padded work
+
+
+@pytest.mark.timeout(600)
+def test_bench_line_contract(built, tmp_path):
+    """`python bench.py` on one GPU (a reduced workload: 60 points of cfg4, whose states differ enough for the split sweep):
+    ONE JSON line with the driver's keys, the roofline object of the dominant launch (and of the second launch beside it),
+    the CPU baseline timed on a bounded sample and checked against the GPU values."""
+    env = dict(os.environ, QK_CACHE_DIR=str(tmp_path / "cache"))
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--points", "60", "--steps", "2", "--warmup", "1", "--cpu-seconds", "2"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=550, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, lines  # one line on stdout, everything else on stderr
+    d = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in d, key
+    assert d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1 and d["unit"] == "entries/s" and d["higher_is_better"] is True and d["vs_baseline"] is None
+    assert "workload" in d["config"] and "model" not in d["config"]
+    assert abs(d["value"] - 60 * 60 / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
+    rf = d["roofline"]
+    for key in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "kernel_ms"):
+        assert key in rf, key
+    assert rf["bound"] == "mfma" and rf["unit"] == "TFLOP/s" and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12 and 0 < rf["frac"] < 1
+    assert rf["kernel"].startswith("qk_sweep_")
+    whole = rf["whole_sweep"]
+    if rf["second_launch"]:  # two launches: their device times add up to the whole sweep, their flops to the plan's
+        s2 = rf["second_launch"]
+        assert abs(rf["kernel_ms"] + s2["kernel_ms"] - whole["kernel_ms"]) < 1e-6 * whole["kernel_ms"]
+        assert abs(rf["algorithmic_tflop_per_launch"] + s2["algorithmic_tflop_per_launch"] - whole["algorithmic_tflop"]) < 1e-9 * whole["algorithmic_tflop"]
+        assert s2["kernel"].startswith("qk_sweep_fused_kernel<8")
+    else:
+        assert abs(rf["kernel_ms"] - whole["kernel_ms"]) < 1e-9
+    cb = d["cpu_baseline"]
+    for key in ("value", "unit", "cores", "kind", "sample"):
+        assert key in cb, key
+    assert cb["kind"] in ("port", "reference") and cb["cores"] >= 1 and cb["value"] > 0 and cb["parity_max_abs_err_vs_gpu"] < 1e-10
+    assert d["config"]["diag_err"] < 1e-11 and d["config"]["sym_err"] == 0.0
