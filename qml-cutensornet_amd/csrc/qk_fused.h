@@ -405,12 +405,10 @@ __device__ __forceinline__ void qkf_p1_dual(QkfTile& t0, QkfTile& t1, v2d (&fr)[
                                             const QkfStream nxt) {
   v4d p1 = {0, 0, 0, 0}, p2 = {0, 0, 0, 0}, p3 = {0, 0, 0, 0}, r1 = {0, 0, 0, 0}, r2 = {0, 0, 0, 0}, r3 = {0, 0, 0, 0};
   v2d fx[4];
-  if (!primed) {
-    qkf_load4(fr, cur);
-    if (HAS1) {
+  if (!primed) qkf_load4(fr, cur);
+  if (HAS1) {  // (the second column block is not carried across units: 16 registers less through phase 2)
 #pragma unroll
-      for (int i = 0; i < 4; ++i) fs[i] = qkf_ldg(cur.base + i * cur.step, cur.off + TILE);
-    }
+    for (int i = 0; i < 4; ++i) fs[i] = qkf_ldg(cur.base + i * cur.step, cur.off + TILE);
   }
 #pragma unroll
   for (int i = 0; i < 4; ++i) fx[i] = qkf_ldx(xp + i * xstep, xoff);
@@ -465,10 +463,6 @@ __device__ __forceinline__ void qkf_p2_dual(const QkfTile& t0, const QkfTile& t1
       }
       fr[i] = qkf_ldg(rb + i * rs, cur.off);
       __builtin_amdgcn_sched_barrier(0);
-    }
-    if (fin && nxt_p1) {
-#pragma unroll
-      for (int i = 0; i < 4; ++i) fs[i] = qkf_ldg(rb + i * rs, cur.off + n1);
     }
     QKF_PRIO_HI();
     {

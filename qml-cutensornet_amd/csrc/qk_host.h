@@ -70,7 +70,6 @@ struct qk_plan {
   qk_stats stats{};
   qk_stats second{};       // pairs / flops / padded_flops / bytes of the class-1 run [n_first, end)
   int64_t n_first = 0;     // pairs [n_first, end) are the class whose sites fit the fused sweep's smaller LDS buffer (== number of pairs: no split)
-  double big_share = 0.0;  // share of this rank's padded work in sites whose X or X' does not fit the fused sweep's larger LDS buffer
   double fit_two = 1.0;  // share of this rank's padded work in sites whose X and X' fit the fused sweep's smaller LDS buffer
   // lazily uploaded copy
   qk_ctx* up_ctx = nullptr;

@@ -127,8 +127,8 @@ static constexpr int QKF_XCAP_ONE = QKF_XCAP_ONE_V, QKF_XCAP_TWO = 4608;  // ele
 #define QKF_DUAL_WPS 3
 #endif
 #define QKF_KERNEL_DUAL qk_sweep_fused_dual_kernel<QKF_DUAL_NW, QKF_XCAP_ONE, QKF_DUAL_WPS>
-static void pair_work(int n, const int32_t* a, const int32_t* b, double* flops, double* padded, double* bytes, double* fit_two = nullptr, double* big = nullptr) {
-  double f = 0, fp = 0, by = 0, ft = 0, bg = 0;
+static void pair_work(int n, const int32_t* a, const int32_t* b, double* flops, double* padded, double* bytes, double* fit_two = nullptr) {
+  double f = 0, fp = 0, by = 0, ft = 0;
   for (int k = 0; k < n; ++k) {
     const double a0 = a[k], a1 = a[k + 1], b0 = b[k], b1 = b[k + 1];
     const double f1 = a0 * b0 * 2 * b1 + 2 * a0 * a1 * b1;
@@ -136,12 +136,10 @@ static void pair_work(int n, const int32_t* a, const int32_t* b, double* flops, 
     f += 8 * std::min(f1, f2);
     const double A0 = pad16(a[k]), A1 = pad16(a[k + 1]), B0 = pad16(b[k]), B1 = pad16(b[k + 1]);
     fp += 8 * (A0 * B0 * 2 * B1 + 2 * A0 * A1 * B1);
-    if (A0 * B0 > QKF_XCAP_ONE || A1 * B1 > QKF_XCAP_ONE) bg += 8 * (A0 * B0 * 2 * B1 + 2 * A0 * A1 * B1);  // X or X' does not fit the larger buffer: a strip site
     if (A0 * B0 <= QKF_XCAP_TWO && A1 * B1 <= QKF_XCAP_TWO) ft += 8 * (A0 * B0 * 2 * B1 + 2 * A0 * A1 * B1);  // X and X' of this site fit the smaller buffer
     by += 16.0 * 2 * (a0 * a1 + b0 * b1);
   }
   if (fit_two) *fit_two = ft;
-  if (big) *big = bg;
   *flops = f;
   *padded = fp;
   *bytes = by + 8;
@@ -246,7 +244,7 @@ extern "C" int qk_plan_create(int32_t n_sites, int32_t nx, const int32_t* x_dims
   int64_t t = 0;  // running index in the global order
   std::vector<int64_t> per_rank(world_size, 0);
   std::vector<int32_t> tile_of;  // locality tile of each pair of this rank
-  double flops = 0, padded = 0, bytes = 0, fit_two = 0, big = 0;
+  double flops = 0, padded = 0, bytes = 0, fit_two = 0;
   const int nbx = (nx + block - 1) / block, nby = (ny + block - 1) / block;
   for (int bj = 0; bj < nby; ++bj)
     for (int bi = 0; bi < nbx; ++bi) {
@@ -273,9 +271,9 @@ extern "C" int qk_plan_create(int32_t n_sites, int32_t nx, const int32_t* x_dims
           p->pairs.push_back(it.i);
           p->pairs.push_back(it.j);
           tile_of.push_back(bj * nbx + bi);
-          double f, fp, by, ft, bg;
-          pair_work(n_sites, x_dims + (int64_t)it.i * stride, y_dims + (int64_t)it.j * stride, &f, &fp, &by, &ft, &bg);
-          flops += f, padded += fp, bytes += by, fit_two += ft, big += bg;
+          double f, fp, by, ft;
+          pair_work(n_sites, x_dims + (int64_t)it.i * stride, y_dims + (int64_t)it.j * stride, &f, &fp, &by, &ft);
+          flops += f, padded += fp, bytes += by, fit_two += ft;
         }
         ++t;
       }
@@ -347,7 +345,6 @@ extern "C" int qk_plan_create(int32_t n_sites, int32_t nx, const int32_t* x_dims
   p->stats.pairs = (int64_t)p->pairs.size() / 2;
   p->stats.flops = flops, p->stats.padded_flops = padded, p->stats.bytes = bytes;
   p->fit_two = padded > 0 ? fit_two / padded : 1.0;
-  p->big_share = padded > 0 ? big / padded : 0.0;
   *out = p;
   return QK_OK;
 }
@@ -775,8 +772,9 @@ extern "C" int qk_gram_values(qk_ctx* c, const qk_mps_set* xs, const qk_mps_set*
   const size_t lds_fused = (size_t)(fused_two ? QKF_XCAP_TWO : QKF_XCAP_ONE) * 16 + lds_meta;
   const int grid = (int)std::min<long long>(units, (long long)(fused ? (fused_two ? 2 : 1) : c->wgs_per_cu) * c->num_cus);
   const char* dual_env = std::getenv("QK_FUSED_DUAL");
-  const bool dual = fused && !fused_two && (dual_env ? std::atoi(dual_env) != 0 : plan->big_share >= 0.5);
-  const bool split = two_runs && !dual;
+  // the 12-wave shape comes in two forms; the dual one (pairs of tiles per wave) is the default (QK_FUSED_DUAL=0: single tiles)
+  const bool dual = fused && !fused_two && (dual_env ? std::atoi(dual_env) != 0 : true);
+  const bool split = two_runs;
   const size_t need = (size_t)(split ? 2 * c->num_cus : grid) * (size_t)chains * 2 * (size_t)(x_plane + t_plane) * sizeof(double);
   if (need > c->scratch_bytes) {
     HIP_TRY(hipStreamSynchronize(c->stream));
@@ -849,10 +847,10 @@ extern "C" int qk_gram_values(qk_ctx* c, const qk_mps_set* xs, const qk_mps_set*
     a.xdata = xs->d_il, a.ydata = ys->d_il;
     a.x_plane = (long long)xs->max_pad * ys->max_pad;  // complex elements per global X buffer (two per workgroup)
     HIP_TRY(hipEventRecord(c->ev0, c->stream));        // the conversion above is not part of the sweep
-    // the dual form (pairs of tiles per wave) pays on sites that run in strips -- uniform bonds 128 / 192 / 256: +8 / +5 / +15 % --
-    // and costs on the small ones (bonds 48: -9 %; the 60-qubit x 6-layer headline set, 11 % of its work in strip sites: -14 %)
+    // the dual form (pairs of tiles per wave: half the A and X fragments per matrix instruction) against single tiles, same box:
+    // uniform bonds 48 / 64 / 96 / 128 / 256: +2 / +4 / +7 / +12 / +19 %; first run of the headline set's split sweep: 255 against 264 ms
     if (fused_two) QKF_KERNEL_TWO<<<dim3(grid), dim3(64 * QKF_TWO_NW), lds_fused, c->stream>>>(a);
-    else if (dual) QKF_KERNEL_DUAL<<<dim3(grid), dim3(64 * QKF_DUAL_NW), lds_fused, c->stream>>>(a);
+    else if (dual && !split) QKF_KERNEL_DUAL<<<dim3(grid), dim3(64 * QKF_DUAL_NW), lds_fused, c->stream>>>(a);
     else if (split) {
       // the plan lists the pairs whose sites fit the smaller LDS buffer behind the others: one 12-wave workgroup per CU for
       // the first run, two 8-wave workgroups per CU for the second, back to back on the stream
@@ -861,7 +859,8 @@ extern "C" int qk_gram_values(qk_ctx* c, const qk_mps_set* xs, const qk_mps_set*
       a2.pairs = a.pairs + 2 * plan->n_first, a2.npairs = np - plan->n_first;
       a2.values = a.values + plan->n_first, a2.z = a.z ? a.z + 2 * plan->n_first : nullptr;
       a2.counter = c->counter + 1;
-      QKF_KERNEL_ONE<<<dim3((unsigned)std::min<long long>(a1.npairs, c->num_cus)), dim3(64 * QKF_ONE_NW), lds_fused, c->stream>>>(a1);
+      if (dual) QKF_KERNEL_DUAL<<<dim3((unsigned)std::min<long long>(a1.npairs, c->num_cus)), dim3(64 * QKF_DUAL_NW), lds_fused, c->stream>>>(a1);
+      else QKF_KERNEL_ONE<<<dim3((unsigned)std::min<long long>(a1.npairs, c->num_cus)), dim3(64 * QKF_ONE_NW), lds_fused, c->stream>>>(a1);
       HIP_TRY(hipEventRecord(c->ev_mid, c->stream));
       QKF_KERNEL_TWO<<<dim3((unsigned)std::min<long long>(a2.npairs, 2ll * c->num_cus)), dim3(64 * QKF_TWO_NW), (size_t)QKF_XCAP_TWO * 16 + lds_meta, c->stream>>>(a2);
       c->last.second_pairs = plan->second.pairs, c->last.second_flops = plan->second.flops, c->last.second_padded_flops = plan->second.padded_flops;

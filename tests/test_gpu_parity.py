@@ -580,7 +580,7 @@ def test_bonds_beyond_the_fused_sweep_take_the_ring_sweep(gpu_ctx):
 
 @pytest.mark.parametrize("n,chi_max,nx,ny,seed", [(14, 40, 3, 3, 1), (18, 100, 3, 2, 2), (20, 150, 2, 3, 3), (22, 260, 2, 2, 4)])
 def test_dual_form_of_the_fused_sweep(gpu_ctx, n, chi_max, nx, ny, seed, monkeypatch):
-    """qk_sweep_fused_dual_kernel (pairs of tiles per wave: sets dominated by strip sites select it on their own): against the
+    """qk_sweep_fused_dual_kernel (pairs of tiles per wave, the default form of the 12-wave shape; QK_FUSED_DUAL=0: single tiles): against the
     oracle on ragged sets of every site class -- LDS-resident in place and ping-pong, single and several strips, odd strip
     widths and odd tile counts (single tiles at the end) -- and against the single-tile form on the same inputs."""
     import qml_cutensornet_amd as Q
@@ -612,7 +612,7 @@ def test_dual_form_of_the_fused_sweep(gpu_ctx, n, chi_max, nx, ny, seed, monkeyp
             assert ("dual" in ctx1.stats()["kernel_name"]) == (dual == "1")
     assert np.abs(out["1"] - z_ref).max() < TOL
     assert np.abs(out["1"] - out["0"]).max() < 1e-13
-    # uniform large bonds: most of the work sits in strip sites, the plan picks the dual form by itself
+    # left to itself the 12-wave shape runs in the dual form
     monkeypatch.delenv("QK_FUSED_DUAL")
     monkeypatch.delenv("QK_FUSED_WGS")
     monkeypatch.delenv("QK_FUSED")
@@ -640,7 +640,7 @@ def test_split_sweep_two_shapes_one_gram(gpu_ctx, monkeypatch):
     with gpu_ctx.upload(xs) as dx:
         K = gpu_ctx.gram(dx)
         st = gpu_ctx.stats()
-        assert st["kernel_name"].startswith("qk_sweep_fused_kernel<12") and st["second_kernel_name"].startswith("qk_sweep_fused_kernel<8")
+        assert st["kernel_name"].startswith("qk_sweep_fused_dual_kernel<12") and st["second_kernel_name"].startswith("qk_sweep_fused_kernel<8")
         assert 0 < st["second_pairs"] < st["pairs"] and 0 < st["second_ms"] < st["kernel_ms"] and 0 < st["second_flops"] < st["flops"]
     monkeypatch.setenv("QK_FUSED_SPLIT", "0")
     with engine.context(0) as ctx1, ctx1.upload(xs) as dx1:
