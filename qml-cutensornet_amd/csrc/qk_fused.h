@@ -26,10 +26,12 @@
 //     loaded like the site tensors), X' is accumulated a block of b' rows at a time (as many as fit the LDS), items in
 //     rounds of (waves x slots), and written to the other global buffer;
 //   * per-site control is a 48-byte record per site, computed by all threads at pair set-up.
-// Two launch shapes (chosen per launch from the plan, qkgram.hip): one 12-wave workgroup per CU (three waves per SIMD at
-// 168 VGPRs, two T slots per wave) with an 8192-element X buffer, or two 8-wave workgroups (128 VGPRs, one slot) with
-// 4608 elements each -- the second workgroup fills the first one's barriers and per-site set-up, which pays while most
-// of the work sits in sites that fit the smaller buffer.  A wave issues in order, so its tails, set-up and load waits
+// Two launch shapes (chosen per launch -- or per run of pairs of a split plan -- in qkgram.hip): one 12-wave workgroup per CU
+// (three waves per SIMD at 168 VGPRs, two tiles per wave) with an 8192-element X buffer -- by default in its DUAL form
+// (qk_sweep_fused_dual_kernel below: the two tiles of a wave share the rows of X and of A, so every A and X fragment feeds
+// two tiles), with independent single tiles in this kernel (QK_FUSED_DUAL=0) -- or two 8-wave workgroups (128 VGPRs, one tile
+// per wave) with 4608 elements each -- the second workgroup fills the first one's barriers and per-site set-up, which pays
+// while most of the work sits in sites that fit the smaller buffer.  A wave issues in order, so its tails, set-up and load waits
 // stall its own matrix stream: the more waves share a SIMD, the better the matrix pipe is fed (8 waves x 4 slots: 482 ms
 // on the headline set, 12 x 2: 452 ms, 16 x 1: 455 ms with a few spilled registers).
 // fp64 only: the f32 MFMA's C layout (C[4q + r][j]) is not an operand layout (the complex64 sweep stays on qk_ring.h).
