@@ -522,9 +522,27 @@ __global__ __launch_bounds__(64 * NW, WPS) void qk_sweep_fused_dual_kernel(const
     return s;
   };
   // the streams of pair `v` of a strip starting at block s0 (v = 2 (tp * mt + ta) + p; column blocks s0 + 2 tp, + 1)
-  auto b_stream = [&](const QkfSite& s, const int s0, const int v) __attribute__((always_inline)) {
+  auto b_stream = [&](const QkfSite& s, const int s0, const int v, const int half) __attribute__((always_inline)) {
     const int pp = v & 1, u = v >> 1, tp = (u * s.inv) >> 20;
-    return QkfStream{s.Bk + pp * s.b2, (unsigned)((q * 2) * s.b2 + (s0 + 2 * tp) * TILE + j), 8 * s.b2};
+    return QkfStream{s.Bk + pp * s.b2, (unsigned)((q * 2) * s.b2 + (s0 + 2 * tp + half) * TILE + j), 8 * s.b2};
+  };
+  // What this wave does in the round that starts at unit r0 of a strip of w blocks with `units` pairs of tiles: pair r0 + wave
+  // -- or, when the units left fill at most half of the waves, ONE tile of pair r0 + wave / 2 (column block 2 tp + (wave & 1)):
+  // the last round of a site then takes half as long (a site of 4 x 4 tiles has 16 pairs: 12 + 4, i.e. 12 pairs + 8 tiles).
+  struct Unit {
+    bool mine, has1;
+    int v, half;
+  };
+  auto unit_of = [&](const QkfSite& s, const int w, const int units, const int r0) __attribute__((always_inline)) {
+    Unit un;
+    const bool halves = 2 * (units - r0) <= NW;
+    un.v = halves ? r0 + (wave >> 1) : r0 + wave;
+    un.half = halves ? (wave & 1) : 0;
+    const int tp = ((un.v >> 1) * s.inv) >> 20;
+    const bool second = 2 * tp + 1 < w;  // the pair has a second tile
+    un.mine = un.v < units && (un.half == 0 || second);
+    un.has1 = !halves && second;
+    return un;
   };
   auto a_stream = [&](const QkfSite& s, const int v) __attribute__((always_inline)) {
     const int pp = v & 1, u = v >> 1, tp = (u * s.inv) >> 20, ta = u - tp * s.mt;
@@ -587,12 +605,12 @@ __global__ __launch_bounds__(64 * NW, WPS) void qk_sweep_fused_dual_kernel(const
           qk_lds_barrier();
         }
         for (int r0 = 0; r0 < units; r0 += NW) {  // (one round on the LDS-resident path)
-          const int v = r0 + wave;
-          const bool mine = v < units;
+          const Unit un = unit_of(sc, w, units, r0);
+          const int v = un.v;
+          const bool mine = un.mine, has1 = un.has1;
           const int u = v >> 1, tp = (u * sc.inv) >> 20, ta = u - tp * mt;
-          const bool has1 = 2 * tp + 1 < w;
           if (mine) {
-            const QkfStream bs = b_stream(sc, s0, v), as = a_stream(sc, v);
+            const QkfStream bs = b_stream(sc, s0, v, un.half), as = a_stream(sc, v);
             const unsigned xoff = (unsigned)(q * a + ta * TILE + j);
             if (xg) {
               if (has1) qkf_p1_dual<true>(T0, T1, fr, fs, primed, bs, (const v2d*)Gc, xoff, 4 * a, sc.nks, as);
@@ -611,28 +629,24 @@ __global__ __launch_bounds__(64 * NW, WPS) void qk_sweep_fused_dual_kernel(const
           }
           if (mine) {
             const int kmax = min(4, (sc.at - ta * TILE + 3) >> 2);
-            // what the wave does next: its pair of the next round of this strip, of the first round of the next strip, or of
+            // what the wave does next: its unit of the next round of this strip, of the first round of the next strip, or of
             // the next site (strip 0, round 0) -- if it has one there
             QkfStream nxt = a_stream(sc, v);
             bool np1 = false;
-            unsigned nd1 = 0;
-            if (v + NW < units) {
-              nxt = b_stream(sc, s0, v + NW), np1 = true;
-              nd1 = (2 * ((((v + NW) >> 1) * sc.inv) >> 20) + 1 < w) ? TILE : 0;
+            if (r0 + NW < units) {
+              const Unit nu = unit_of(sc, w, units, r0 + NW);
+              if (nu.mine) nxt = b_stream(sc, s0, nu.v, nu.half), np1 = true;
             } else if (s0 + W < nt) {
               const int w2 = min(W, nt - s0 - W);
-              if (wave < 2 * mt * ((w2 + 1) >> 1)) {
-                nxt = b_stream(sc, s0 + W, wave), np1 = true;
-                nd1 = (2 * (((wave >> 1) * sc.inv) >> 20) + 1 < w2) ? TILE : 0;
-              }
+              const Unit nu = unit_of(sc, w2, 2 * mt * ((w2 + 1) >> 1), 0);
+              if (nu.mine) nxt = b_stream(sc, s0 + W, nu.v, nu.half), np1 = true;
             } else if (k + 1 < ns) {
               const int w2 = min(sn.W, sn.nt);
-              if (wave < 2 * sn.mt * ((w2 + 1) >> 1)) {
-                nxt = b_stream(sn, 0, wave), np1 = true;
-                nd1 = (2 * (((wave >> 1) * sn.inv) >> 20) + 1 < w2) ? TILE : 0;
-              }
+              const Unit nu = unit_of(sn, w2, 2 * sn.mt * ((w2 + 1) >> 1), 0);
+              if (nu.mine) nxt = b_stream(sn, 0, nu.v, nu.half), np1 = true;
             }
-            lds_v2d* const xo = XL + ob + (2 * tp) * TILE * a2;
+            const unsigned nd1 = 0;
+            lds_v2d* const xo = XL + ob + (2 * tp + un.half) * TILE * a2;
             if (has1) {
               if (kmax == 4) qkf_p2_dual<true, true>(T0, T1, fr, fs, a_stream(sc, v), a2, sc.nn, 4, xo, q, j, nxt, np1, nd1);
               else qkf_p2_dual<false, true>(T0, T1, fr, fs, a_stream(sc, v), a2, sc.nn, kmax, xo, q, j, nxt, np1, nd1);
