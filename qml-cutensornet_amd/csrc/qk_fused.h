@@ -527,7 +527,7 @@ __global__ __launch_bounds__(64 * NW, WPS) void qk_sweep_fused_dual_kernel(const
     return QkfStream{s.Bk + pp * s.b2, (unsigned)((q * 2) * s.b2 + (s0 + 2 * tp + half) * TILE + j), 8 * s.b2};
   };
   // What this wave does in the round that starts at unit r0 of a strip of w blocks with `units` pairs of tiles: pair r0 + wave
-  // -- or, when the units left fill at most half of the waves, ONE tile of pair r0 + wave / 2 (column block 2 tp + (wave & 1)):
+  // -- or, when the units left fill at most half of the waves, ONE tile of a pair (column block 2 tp or 2 tp + 1):
   // the last round of a site then takes half as long (a site of 4 x 4 tiles has 16 pairs: 12 + 4, i.e. 12 pairs + 8 tiles).
   struct Unit {
     bool mine, has1;
@@ -535,9 +535,11 @@ __global__ __launch_bounds__(64 * NW, WPS) void qk_sweep_fused_dual_kernel(const
   };
   auto unit_of = [&](const QkfSite& s, const int w, const int units, const int r0) __attribute__((always_inline)) {
     Unit un;
-    const bool halves = 2 * (units - r0) <= NW;
-    un.v = halves ? r0 + (wave >> 1) : r0 + wave;
-    un.half = halves ? (wave & 1) : 0;
+    const int left = units - r0;
+    const bool halves = 2 * left <= NW;
+    // (first tiles to waves 0 .. left - 1, second tiles to the next `left` waves: consecutive waves sit on different SIMDs)
+    un.half = (halves && wave >= left) ? 1 : 0;
+    un.v = r0 + wave - (un.half ? left : 0);
     const int tp = ((un.v >> 1) * s.inv) >> 20;
     const bool second = 2 * tp + 1 < w;  // the pair has a second tile
     un.mine = un.v < units && (un.half == 0 || second);
