@@ -64,7 +64,7 @@ typedef struct qk_plan qk_plan;       /* ordered list of (x, y) pairs assigned t
  * on the context's stream (0 until the events have completed). */
 typedef struct qk_stats {
   int64_t pairs;
-  double flops;        /* sum over pairs and sites of 8*(a*b*2*b' + 2*a*a'*b')        */
+  double flops;        /* sum over pairs and sites of 8*min(a*b*2*b' + 2*a*a'*b', a*b*2*a' + 2*b*a'*b'): the cheaper association per site */
   double padded_flops; /* the same with every bond rounded up to the MFMA tile (16)   */
   double bytes;        /* sum over pairs of 16*2*sum_k(a_k a_k+1 + b_k b_k+1) + 8     */
   double kernel_ms;    /* device time of the last sweep launch                        */
@@ -79,7 +79,11 @@ typedef struct qk_stats {
   double second_flops, second_padded_flops, second_bytes;
   double second_ms;     /* device time of the second launch (kernel_ms covers both)    */
   int32_t second_kernel; /* QK_KERNEL_FUSED2, or QK_KERNEL_NONE                          */
-  int32_t reserved;
+  int32_t queues;        /* device work queues of the launch: 8 per class of pairs (one per XCD), 1 = one list */
+  /* Tail accounting from device clocks (first workgroup start, first and last workgroup exit per launch): the share of a
+   * launch's duration during which the chip was draining -- some workgroups had run out of work, the last one had not.
+   * 0 for kernels that do not record it.  At a 1/8 share of the Gram the tails weigh eight times more than on one GPU.   */
+  double tail_frac, second_tail_frac;
 } qk_stats;
 
 /* sweep kernels of qk_gram_values (qk_stats.kernel) */
@@ -181,6 +185,16 @@ int qk_plan_stats(const qk_plan* plan, qk_stats* out); /* algorithmic flops/byte
  * sites that fit the site-fused kernel's smaller LDS buffer; qk_gram_values sweeps the two runs with the kernel's two shapes
  * (one launch each).  == num_pairs when the plan holds (nearly) one class only.                                          */
 int64_t qk_plan_first_run(const qk_plan* plan);
+/* XCD-aware work queues (default plans; QK_PLAN_XCD=0 in the environment or an explicit `block` gives the flat cost-ordered
+ * list).  The states are sorted by weight, the Gram is cut into tiles of QK_PLAN_TILE x QK_PLAN_TILE (default 8 x 8) pairs in
+ * that order -- the pairs of a tile share their x and y states and cost about the same --, the tiles are dealt heaviest
+ * first to the least loaded rank and, per run of this rank's list, to 8 queues: queue s of the first run = pairs
+ * [qstart[s], qstart[s+1]), s = 0..7, of the second run s = 8..15 (qstart[8] = qk_plan_first_run, qstart[16] = num_pairs).
+ * On the device a workgroup reads the id of the XCD it runs on (8 XCDs with a private 4 MiB L2 each) and drains that queue
+ * first, then steals from the others: the workgroups that share an L2 stream the same few states.  Replaces the chunk
+ * bookkeeping of G:154, 331-334, 384-385 like the rest of the plan.  Returns the number of queues (16, or 1 for a flat
+ * list: then qstart[0] = 0 and qstart[1..16] = num_pairs); qstart may be NULL.                                            */
+int qk_plan_queues(const qk_plan* plan, int64_t* qstart /* [17] */);
 
 /* ---- the hot path -----------------------------------------------------------
  * qk_gram_values: for every pair p of the plan compute z_p = <x_i|y_j> and write
@@ -188,13 +202,19 @@ int64_t qk_plan_first_run(const qk_plan* plan);
  *     z_dev[2p], z_dev[2p+1] = re, im of z_p  (optional, may be NULL)
  * One persistent launch; returns after enqueueing (asynchronous).
  * yset = NULL means Y is X.
- * The sweep kernel is chosen from the two sets' largest padded bond and precision: 16 (fp64) -> one pair per
- * wavefront, entirely in registers; <= 32 -> fp64: one pair per wavefront with 2 x 2 register tiles, complex64: X and T
- * resident in LDS, site tensors streamed; larger fp64 bonds -> the
- * site-fused sweep (X in LDS, T in registers, qk_fused.h); complex64 sets and bonds > 512 -> the ring sweep (X / T in
- * an L2-resident scratch).  All compute the same chain of complex GEMMs on the matrix cores and agree to rounding
- * (tests/test_gpu_parity.py); QK_WAVE=0 / QK_WAVE2=0 / QK_SMALL=0 / QK_FUSED=0 in the environment fall back to the next more
- * general one, QK_FUSED=2 uses the fused sweep from bond 17, QK_FUSED_WGS=1|2 fixes its workgroups per CU.          */
+ * The sweep kernel is chosen from the two sets' largest padded bond and precision:
+ *   16, fp64            one pair per wavefront, entirely in registers (qk_sweep_wave_kernel);
+ *   <= 32, fp64         one pair per wavefront with 2 x 2 register tiles, fed through a per-wave LDS-DMA ring
+ *                       (qk_sweep_wave2_kernel<3, double>);
+ *   <= 32, complex64    the SAME kernel on the complex64 image: single-precision storage, fp64 arithmetic
+ *                       (qk_sweep_wave2_kernel<3, float>); with QK_WAVE2=0 | 2 the LDS-resident small-bond sweep in
+ *                       complex64 arithmetic on the fp32 matrix cores (qk_sweep_small_kernel<float>);
+ *   larger, fp64        the site-fused sweep (X in LDS, T in registers, qk_fused.h), bonds up to 512;
+ *   larger, complex64   and fp64 bonds > 512: the ring sweep (X / T in an L2-resident scratch; complex64 arithmetic on
+ *                       the fp32 matrix cores for complex64 sets).
+ * All compute the same chain of complex GEMMs on the matrix cores and agree to rounding (tests/test_gpu_parity.py);
+ * QK_WAVE=0 / QK_WAVE2=0 / QK_SMALL=0 / QK_FUSED=0 in the environment fall back to the next more general one, QK_FUSED=2
+ * uses the fused sweep from bond 17, QK_FUSED_WGS=1|2 fixes its workgroups per CU.                                   */
 int qk_gram_values(qk_ctx* ctx, const qk_mps_set* xset, const qk_mps_set* yset, const qk_plan* plan,
                    double* values_dev, double* z_dev);
 
@@ -219,6 +239,42 @@ int qk_gram_host(qk_ctx* ctx, const qk_mps_set* xset, const qk_mps_set* yset, do
 int qk_overlaps_host(qk_ctx* ctx, const qk_mps_set* xset, const qk_mps_set* yset, double* out);
 
 int qk_get_stats(qk_ctx* ctx, qk_stats* out);
+
+/* ---- profiler ranges -----------------------------------------------------------------------------------------
+ * roctx ranges (rocprofv3 --marker-trace) named "qk:build", "qk:upload", "qk:sweep", "qk:scatter", "qk:allgather_values",
+ * "qk:allgather_sets" are opened by the library around its own phases -- the reference's MPI.Wtime() sites G:209-231
+ * (circuit simulation), G:379-381 (vdot) and G:341-352 (round robin) --; callers use the same two entry points for theirs.
+ * No-ops unless a profiler is attached (or QK_ROCTX=1): the marker library is resolved at first use.                  */
+int qk_range_push(const char* name);
+int qk_range_pop(void);
+
+/* ---- multi-GPU: one process, k MI355X of one node, RCCL over xGMI ----------------------------------------------
+ * Replaces the reference's communicator plumbing: rank / chunk bookkeeping G:149-199 (one MPI process per GPU, device =
+ * rank % n_devices, G:152), the ring of pickled MPS G:341-352, 415-419 and the final comm.reduce(kernel_mat, SUM) G:428
+ * (which only ever gathers: every rank's matrix is zero outside its own tiles).
+ *   qk_comm_init_all      a context per device (device_ids = NULL: devices 0..n-1) and an RCCL communicator clique
+ *                         (ncclCommInitAll); RCCL is loaded at run time (librccl.so.1), the single-GPU entry points do not
+ *                         need it.  qk_comm_ctx(comm, r) is rank r's context: sets for rank r are created on it.
+ *   qk_mps_set_allgather  local[r] = the states [lo[r], lo[r] + n_r) that rank r built or uploaded (NULL = an empty share);
+ *                         ONE ncclAllGather of the packed images and full_out[r] = the whole set of `total` states on
+ *                         every device (the caller destroys them).
+ *   qk_gram_sharded       xsets[r] / ysets[r] = the whole set(s) on device r (ysets = NULL: symmetric Gram).  Every device
+ *                         sweeps rank r's share of the plan (qk_plan_create(world = n, rank = r)) in one launch, the packed
+ *                         values meet in ONE ncclAllGather, every device scatters (and mirrors) its own dense K; rank 0's K
+ *                         is copied to out_host[ny][ld] (may be NULL) and the call returns when every device is done.
+ *                         Plans and buffers are kept while the same sets come back.
+ *   qk_comm_device_gram   device r's dense K of the last call (valid until the next one);  qk_comm_stats: rank r's sweep
+ *                         statistics and the device time between enqueueing the all-gather on rank 0's stream and its
+ *                         completion (includes waiting for the slowest rank; the reference's r0_RR_recv key).           */
+typedef struct qk_comm qk_comm;
+int qk_comm_init_all(int32_t n_devices, const int32_t* device_ids, qk_comm** out);
+int qk_comm_destroy(qk_comm* comm);
+int32_t qk_comm_size(const qk_comm* comm);
+qk_ctx* qk_comm_ctx(qk_comm* comm, int32_t rank);
+int qk_mps_set_allgather(qk_comm* comm, qk_mps_set* const* local, const int32_t* lo, int32_t total, qk_mps_set** full_out);
+int qk_gram_sharded(qk_comm* comm, qk_mps_set* const* xsets, qk_mps_set* const* ysets, double* out_host, int64_t ld);
+int qk_comm_device_gram(qk_comm* comm, int32_t rank, const double** k_dev);
+int qk_comm_stats(const qk_comm* comm, int32_t rank, qk_stats* out, double* allgather_ms);
 
 /* Device self-test of the f64 MFMA fragment maps the kernels rely on (returns
  * 0 if the 16x16x4 product of two known matrices matches the host result). */

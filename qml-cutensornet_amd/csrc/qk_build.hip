@@ -761,6 +761,7 @@ extern "C" int qk_build_mps(qk_ctx* c, int32_t n_states, int32_t n_qubits, int32
   if (n_states <= 0 || n_qubits <= 0 || n_ops < 0) return qk_fail(QK_EINVAL, "qk_build_mps: empty problem (%d states, %d qubits, %d gates)", n_states, n_qubits, n_ops);
   if (max_bond < 2 || max_bond > 1024) return qk_fail(QK_EINVAL, "qk_build_mps: max_bond %d outside 2..1024", max_bond);
   *out = nullptr;
+  QkRangeGuard range_("qk:build");
   HIP_TRY(hipSetDevice(c->device));
   const int cap = max_bond;
   size_t lds_meta = (size_t)2 * cap * sizeof(double) + (size_t)2 * cap * sizeof(int) + (size_t)(n_qubits + 1) * sizeof(int);

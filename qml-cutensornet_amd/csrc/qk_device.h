@@ -28,11 +28,53 @@ struct SweepArgs {
   double* scratch;
   long long x_plane;  // doubles per X plane
   long long t_plane;  // doubles per T plane
-  unsigned long long* counter;
+  unsigned long long* counter;  // work-queue heads: head of queue s at counter[QK_QSTRIDE * s] (kernels without XCD queues use counter[0] only)
+  int nq;                       // queues of this launch: 8 (one per XCD) or 16 (two classes of pairs x 8); <= 1: one list [0, npairs)
+  long long qstart[17];         // queue s holds the pairs [qstart[s], qstart[s + 1]) of this launch's list
+  unsigned long long* tail;     // per-launch device clocks (s_memrealtime, 100 MHz): [0] first workgroup start, [1] first workgroup exit, [4] last workgroup exit
   unsigned long long* prof;  // diagnostic build only: cycle sums per section (see QK_VARIANT=9)
   int debug_flags;           // timing experiments only (QK_DEBUG_FLAGS): bit 0 = skip epilogue stores, bit 1 = skip steady-state fetch/stash, bit 2 = skip MFMAs, bit 3 = skip steady-state barriers (all give WRONG results)
   int prio_mode;             // 0: none; 1: second half of the grid at s_setprio 1; 2: odd blocks at s_setprio 1
 };
+
+static constexpr int QK_QSTRIDE = 16;  // queue heads 128 bytes apart
+static constexpr int QK_NQ_MAX = 16;
+
+// The XCD this wave runs on (0..7): blocks are dealt round-robin over the 8 XCDs, each with its own 4 MiB L2.
+__device__ __forceinline__ int qk_xcc_id() { return __builtin_amdgcn_s_getreg((3 << 11) | 20) & 7; }  // hwreg(HW_REG_XCC_ID, 0, 4)
+
+// Next pair of this launch for a workgroup on XCD `xcc` (called by ONE lane): the plan lists the pairs as 8 queues per class
+// (qk_plan_create: tiles of pairs that share their x and y states, dealt to the queues), a workgroup drains the queue of its
+// own XCD first -- so that the workgroups that share an L2 stream the same few states -- and then steals from the others.
+// Returns -1 when every queue is empty.
+__device__ __forceinline__ long long qk_pull(const SweepArgs& g, const int xcc) {
+  if (g.nq <= 1) {
+    const long long p = (long long)atomicAdd(g.counter, 1ull);
+    return p < g.npairs ? p : -1;
+  }
+  for (int s = 0; s < g.nq; ++s) {
+    const int qd = ((xcc + s) & 7) + (s & 8);
+    const long long n = g.qstart[qd + 1] - g.qstart[qd];
+    if (n <= 0) continue;
+    const long long t = (long long)atomicAdd(g.counter + QK_QSTRIDE * qd, 1ull);
+    if (t < n) return g.qstart[qd] + t;
+  }
+  return -1;
+}
+
+// Device clocks of a launch for the tail accounting (one lane per workgroup): when the first workgroup started, when the first
+// one ran out of work and when the last one did -- (last - first exit) / (last exit - first start) is the share of the launch
+// during which the chip was draining.
+__device__ __forceinline__ void qk_tail_start(const SweepArgs& g) {
+  if (g.tail) atomicMin(g.tail, (unsigned long long)__builtin_amdgcn_s_memrealtime());
+}
+__device__ __forceinline__ void qk_tail_exit(const SweepArgs& g) {
+  if (g.tail) {
+    const unsigned long long t = __builtin_amdgcn_s_memrealtime();
+    atomicMin(g.tail + 1, t);
+    atomicMax(g.tail + 4, t);
+  }
+}
 
 // Workgroup barrier that publishes LDS writes only: it does NOT drain outstanding global loads or LDS-DMAs
 // (a __syncthreads() would wait vmcnt(0) and cancel the prefetch that is meant to stay in flight).

@@ -250,12 +250,14 @@ __global__ __launch_bounds__(64 * NW, WPS) void qk_sweep_fused_kernel(const Swee
 #else
 #define QKF_STAMP(i)
 #endif
+  const int xcc = qk_xcc_id();
+  if (tid == 0) qk_tail_start(g);
   for (;;) {
-    if (tid == 0) *slot = (long long)atomicAdd(g.counter, 1ull);
+    if (tid == 0) *slot = qk_pull(g, xcc);  // this XCD's queue first: the workgroups that share an L2 stream the same few states
     __syncthreads();
     const long long p = *slot;
     __syncthreads();
-    if (p >= g.npairs) break;
+    if (p < 0) break;
     const int xi = g.pairs[2 * p], yj = g.pairs[2 * p + 1];
     for (int e = tid; e < ns; e += NT) {  // site e of the pair
       const int a = g.xdims[(long long)xi * n1 + e], a2 = g.xdims[(long long)xi * n1 + e + 1];
@@ -314,7 +316,7 @@ __global__ __launch_bounds__(64 * NW, WPS) void qk_sweep_fused_kernel(const Swee
           qk_lds_barrier();
         }
         QKF_STAMP(6);  // strip zeroing
-        for (int r0 = 0; r0 < items; r0 += NW * S) {  // (one round on the LDS-resident path)
+        for (int r0 = 0; r0 < items; r0 += NW * S) {  // (LDS-resident sites: one round, or several when X and X' sit side by side)
           const int L = min(S, (items - r0 + NW - 1) / NW);  // slots in use this round (the same for every wave)
           const bool multi = L > 1;
           const int it0 = r0 + wave;          // this wave's items: it0, it0 + NW, ...
@@ -388,6 +390,7 @@ __global__ __launch_bounds__(64 * NW, WPS) void qk_sweep_fused_kernel(const Swee
     }
     __syncthreads();
   }
+  if (tid == 0) qk_tail_exit(g);
 #ifdef QKF_PROF
   if (lane == 0) {
     pf[7] = __builtin_amdgcn_s_memtime() - pt0;
@@ -550,12 +553,14 @@ __global__ __launch_bounds__(64 * NW, WPS) void qk_sweep_fused_dual_kernel(const
     const int pp = v & 1, u = v >> 1, tp = (u * s.inv) >> 20, ta = u - tp * s.mt;
     return QkfStream{s.Ak + pp * s.a2, (unsigned)(((ta * TILE + q) * 2) * s.a2 + j), 8 * s.a2};
   };
+  const int xcc = qk_xcc_id();
+  if (tid == 0) qk_tail_start(g);
   for (;;) {
-    if (tid == 0) *slot = (long long)atomicAdd(g.counter, 1ull);
+    if (tid == 0) *slot = qk_pull(g, xcc);  // this XCD's queue first: the workgroups that share an L2 stream the same few states
     __syncthreads();
     const long long p = *slot;
     __syncthreads();
-    if (p >= g.npairs) break;
+    if (p < 0) break;
     const int xi = g.pairs[2 * p], yj = g.pairs[2 * p + 1];
     for (int e = tid; e < ns; e += NT) {
       const int a = g.xdims[(long long)xi * n1 + e], a2 = g.xdims[(long long)xi * n1 + e + 1];
@@ -606,7 +611,7 @@ __global__ __launch_bounds__(64 * NW, WPS) void qk_sweep_fused_dual_kernel(const
           for (int e = tid; e < w * TILE * a2; e += NT) XL[e] = (v2d){0.0, 0.0};
           qk_lds_barrier();
         }
-        for (int r0 = 0; r0 < units; r0 += NW) {  // (one round on the LDS-resident path)
+        for (int r0 = 0; r0 < units; r0 += NW) {  // (LDS-resident sites: one round, or several when X and X' sit side by side)
           const Unit un = unit_of(sc, w, units, r0);
           const int v = un.v;
           const bool mine = un.mine, has1 = un.has1;
@@ -682,6 +687,7 @@ __global__ __launch_bounds__(64 * NW, WPS) void qk_sweep_fused_dual_kernel(const
     }
     __syncthreads();
   }
+  if (tid == 0) qk_tail_exit(g);
 }
 
 // split planes (re | im) of a set image -> interleaved complex (complex128 for double, complex64 for float), same offsets;
@@ -750,12 +756,14 @@ __global__ __launch_bounds__(64, 2) void qk_sweep_wave2_kernel(const SweepArgs g
     const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)((unsigned long long)v >> 32));
     return (long long)(((unsigned long long)hi << 32) | lo);
   };
+  const int xcc = qk_xcc_id();
+  if (lane == 0) qk_tail_start(g);
   for (;;) {
-    if (lane == 0) slot = (long long)atomicAdd(g.counter, 1ull);
+    if (lane == 0) slot = qk_pull(g, xcc);
     __syncthreads();
     const long long p = unil(slot);
     __syncthreads();
-    if (p >= g.npairs) break;
+    if (p < 0) break;
     // per-pair tables through the scalar cache (wave-uniform addresses in the constant address space): a vector load
     // per site and table would put its whole latency in front of the site's first tensor load
     typedef const __attribute__((address_space(4))) int* sint_p;
@@ -943,4 +951,5 @@ __global__ __launch_bounds__(64, 2) void qk_sweep_wave2_kernel(const SweepArgs g
       }
     }
   }
+  if (lane == 0) qk_tail_exit(g);
 }

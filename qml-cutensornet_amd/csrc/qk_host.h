@@ -11,6 +11,10 @@
 #include <vector>
 
 int qk_fail(int code, const char* fmt, ...) __attribute__((format(printf, 2, 3)));  // sets qk_last_error(), returns code
+struct QkRangeGuard {  // a roctx range (qk_range_push / qk_range_pop) that closes on every exit path
+  explicit QkRangeGuard(const char* n) { qk_range_push(n); }
+  ~QkRangeGuard() { qk_range_pop(); }
+};
 
 #define HIP_TRY(expr)                                                                                 \
   do {                                                                                                \
@@ -30,7 +34,8 @@ struct qk_ctx {
   bool ev_pending = false;
   double* scratch = nullptr;
   size_t scratch_bytes = 0;
-  unsigned long long* counter = nullptr;
+  unsigned long long* counter = nullptr;  // work-queue heads (QK_NQ_MAX of them, QK_QSTRIDE apart) + 2 x 4 tail clocks behind them
+  bool tail_pending = false;
   unsigned long long* prof = nullptr;  // 8 cycle sums of the diagnostic variant
   int variant = 20;    // 20 = the shipped kernels.  Anything else exists only in libqklab.so (QK_VARIANT there: 17 = lean register-staged
                        // sweep; 0, 2, 12, 13, 14, 16, 21, 23 = other kernels kept for A/B; 9, 19 = instrumented)
@@ -70,6 +75,8 @@ struct qk_plan {
   qk_stats stats{};
   qk_stats second{};       // pairs / flops / padded_flops / bytes of the class-1 run [n_first, end)
   int64_t n_first = 0;     // pairs [n_first, end) are the class whose sites fit the fused sweep's smaller LDS buffer (== number of pairs: no split)
+  int nq = 1;                 // device work queues: 1 = one list; 16 = two classes of pairs x 8 XCD queues (the second class may be empty)
+  int64_t qstart[17] = {0};   // queue s = pairs [qstart[s], qstart[s + 1]) of this rank's list; queues 8..15 = the class-1 run
   double fit_two = 1.0;  // share of this rank's padded work in sites whose X and X' fit the fused sweep's smaller LDS buffer
   // lazily uploaded copy
   qk_ctx* up_ctx = nullptr;

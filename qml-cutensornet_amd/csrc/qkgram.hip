@@ -48,6 +48,46 @@ int qk_fail(int code, const char* fmt, ...) {
 
 extern "C" const char* qk_last_error(void) { return g_err.c_str(); }
 
+// ----------------------------------------------------------------------------------------
+// roctx ranges around the phases of the path (build / upload / sweep / all-gather / scatter: the reference's timing sites
+// G:379-381 and its profiling keys), so that ONE `rocprofv3 --marker-trace --kernel-trace` run yields the phase table.
+// The marker library is resolved at first use -- only when a profiler is attached (rocprofv3 preloads its tool library)
+// or QK_ROCTX=1 -- and the calls are no-ops otherwise.
+// ----------------------------------------------------------------------------------------
+#include <dlfcn.h>
+namespace {
+struct Roctx {
+  int (*push)(const char*) = nullptr;
+  int (*pop)() = nullptr;
+};
+Roctx& roctx() {
+  static Roctx r = [] {
+    Roctx x;
+    const char* e = std::getenv("QK_ROCTX");
+    const char* pre = std::getenv("LD_PRELOAD");
+    const bool attached = std::getenv("ROCP_TOOL_LIBRARIES") || (pre && std::strstr(pre, "rocprofiler"));
+    if (e ? std::atoi(e) == 0 : !attached) return x;
+    void* h = nullptr;
+    for (const char* name : {"librocprofiler-sdk-roctx.so.1", "librocprofiler-sdk-roctx.so", "libroctx64.so.4", "libroctx64.so"})
+      if ((h = dlopen(name, RTLD_NOW | RTLD_GLOBAL))) break;
+    if (!h) return x;
+    x.push = reinterpret_cast<int (*)(const char*)>(dlsym(h, "roctxRangePushA"));
+    x.pop = reinterpret_cast<int (*)()>(dlsym(h, "roctxRangePop"));
+    if (!x.push || !x.pop) x.push = nullptr, x.pop = nullptr;
+    return x;
+  }();
+  return r;
+}
+}  // namespace
+extern "C" int qk_range_push(const char* name) {
+  Roctx& r = roctx();
+  return (r.push && name) ? r.push(name) : 0;
+}
+extern "C" int qk_range_pop(void) {
+  Roctx& r = roctx();
+  return r.pop ? r.pop() : 0;
+}
+
 static inline int pad16(int x) { return (x + TILE - 1) / TILE * TILE; }
 
 // a device allocation that is released on every exit path (HIP_TRY returns early)
@@ -158,6 +198,159 @@ static double fused_cost(int n, const int32_t* a, const int32_t* b) {
   return c;
 }
 
+// ----------------------------------------------------------------------------------------
+// The tiled plan: XCD-aware work queues (default; QK_PLAN_XCD=0 or an explicit locality `block` selects the flat list).
+// An MI355X has 8 XCDs with a private 4 MiB L2 each, and blocks are dealt to them round-robin.  With one cost-ordered list
+// the 32 (or 64) workgroups that share an L2 stream 64 unrelated states through it (measured hit rate 39 %, 2.5-3 x the
+// algorithmic bytes at the L2 <-> fabric boundary).  Here the states are sorted by weight, the Gram is cut into tiles of T x T
+// pairs in that order -- pairs of a tile share their T x states and T y states and cost about the same, so the workgroups
+// sweeping a tile walk the chain at a similar pace --, the tiles are dealt (heaviest first, to the least loaded) to the
+// ranks and, per class of pairs, to 8 queues; a workgroup drains the queue of its own XCD and then steals (qk_pull).
+// ----------------------------------------------------------------------------------------
+static void plan_tiled(qk_plan* p, const int n_sites, const int nx, const int32_t* x_dims, const int ny, const int32_t* y_dims, const bool sym, const bool orient, const int world,
+                       const int rank, const int T) {
+  const int stride = n_sites + 1;
+  auto order_of = [&](const int n, const int32_t* dims) {
+    std::vector<double> w((size_t)n);
+    for (int s = 0; s < n; ++s) {
+      const int32_t* d = dims + (int64_t)s * stride;
+      double acc = 0;
+      for (int k = 0; k < n_sites; ++k) {
+        const double A0 = pad16(d[k]), A1 = pad16(d[k + 1]);
+        acc += A0 * A1 * (A0 + A1);
+      }
+      w[(size_t)s] = acc;
+    }
+    std::vector<int> o((size_t)n);
+    std::iota(o.begin(), o.end(), 0);
+    std::stable_sort(o.begin(), o.end(), [&](const int u, const int v) { return w[(size_t)u] > w[(size_t)v]; });
+    return o;
+  };
+  const std::vector<int> ox = order_of(nx, x_dims), oy = sym ? ox : order_of(ny, y_dims);
+  struct Item {
+    int32_t i, j;
+    double f, fp, by, ft;
+  };
+  struct Tile {
+    int64_t start, count;
+    double cost;
+  };
+  std::vector<Item> items;
+  std::vector<Tile> tiles;
+  const int nbx = (nx + T - 1) / T, nby = (ny + T - 1) / T;
+  for (int bj = 0; bj < nby; ++bj)
+    for (int bi = 0; bi < nbx; ++bi) {
+      if (sym && bi > bj) continue;
+      Tile t{(int64_t)items.size(), 0, 0.0};
+      for (int v = bj * T; v < std::min(ny, (bj + 1) * T); ++v)
+        for (int u = bi * T; u < std::min(nx, (bi + 1) * T); ++u) {
+          if (sym && u > v) continue;  // positions in the weight order: every unordered pair once
+          int xi = ox[(size_t)u], yj = oy[(size_t)v];
+          if (sym && !orient && xi > yj) std::swap(xi, yj);  // the plain symmetric list names a pair as i <= j
+          if (orient && xi != yj && fused_cost(n_sites, x_dims + (int64_t)yj * stride, y_dims + (int64_t)xi * stride) < fused_cost(n_sites, x_dims + (int64_t)xi * stride, y_dims + (int64_t)yj * stride))
+            std::swap(xi, yj);
+          Item it{xi, yj, 0, 0, 0, 0};
+          pair_work(n_sites, x_dims + (int64_t)xi * stride, y_dims + (int64_t)yj * stride, &it.f, &it.fp, &it.by, &it.ft);
+          items.push_back(it);
+          t.cost += it.fp;
+        }
+      t.count = (int64_t)items.size() - t.start;
+      if (t.count) tiles.push_back(t);
+    }
+  std::vector<int> by_cost(tiles.size());
+  std::iota(by_cost.begin(), by_cost.end(), 0);
+  std::stable_sort(by_cost.begin(), by_cost.end(), [&](const int u, const int v) { return tiles[(size_t)u].cost > tiles[(size_t)v].cost; });
+  if (world > 1) {
+    // several ranks: the lightest tiles (the last 3 % of the work) are dealt pair by pair, so that the shares end level to a
+    // pair's cost instead of a tile's (cut into one-pair tiles here; they keep their place behind the whole tiles)
+    double total = 0, acc = 0;
+    for (const Tile& t : tiles) total += t.cost;
+    std::vector<Tile> cut;
+    std::vector<int> order;
+    for (const int t : by_cost) {
+      acc += tiles[(size_t)t].cost;
+      if (acc <= 0.97 * total || tiles[(size_t)t].count == 1) {
+        order.push_back((int)cut.size());
+        cut.push_back(tiles[(size_t)t]);
+      } else {
+        std::vector<int64_t> q((size_t)tiles[(size_t)t].count);
+        std::iota(q.begin(), q.end(), tiles[(size_t)t].start);
+        std::stable_sort(q.begin(), q.end(), [&](const int64_t u, const int64_t v) { return items[(size_t)u].fp > items[(size_t)v].fp; });
+        for (const int64_t e : q) {
+          order.push_back((int)cut.size());
+          cut.push_back(Tile{e, 1, items[(size_t)e].fp});
+        }
+      }
+    }
+    tiles.swap(cut), by_cost.swap(order);
+    std::stable_sort(by_cost.begin(), by_cost.end(), [&](const int u, const int v) { return tiles[(size_t)u].cost > tiles[(size_t)v].cost; });
+  }
+  // tiles to ranks: heaviest first, each to the least loaded rank
+  std::vector<double> load((size_t)world, 0.0);
+  std::vector<int64_t> per_rank((size_t)world, 0);
+  std::vector<int> mine;
+  for (const int t : by_cost) {
+    const int r = (int)(std::min_element(load.begin(), load.end()) - load.begin());
+    load[(size_t)r] += tiles[(size_t)t].cost, per_rank[(size_t)r] += tiles[(size_t)t].count;
+    if (r == rank) mine.push_back(t);
+  }
+  // classes of this rank's pairs (see qk_plan_create): class 1 = nearly all of the work fits the fused sweep's smaller LDS buffer
+  double split = 0.75;
+  if (const char* e = std::getenv("QK_PLAN_SPLIT")) split = std::atof(e);
+  double flops = 0, padded = 0, bytes = 0, fit_two = 0, small_work = 0;
+  for (const int t : mine)
+    for (int64_t q = tiles[(size_t)t].start; q < tiles[(size_t)t].start + tiles[(size_t)t].count; ++q) {
+      const Item& it = items[(size_t)q];
+      flops += it.f, padded += it.fp, bytes += it.by, fit_two += it.ft;
+      if (it.fp > 0 && it.ft >= split * it.fp) small_work += it.fp;
+    }
+  const bool two_classes = !(small_work < 0.05 * padded || small_work > 0.95 * padded);
+  auto cls_of = [&](const Item& it) { return (two_classes && it.fp > 0 && it.ft >= split * it.fp) ? 1 : 0; };
+  p->pairs.clear(), p->groups.clear();
+  p->second = qk_stats{};
+  p->nq = QK_NQ_MAX;
+  for (int c = 0; c < 2; ++c) {
+    // this class's share of each tile, tiles to the 8 queues heaviest first / least loaded
+    std::vector<std::pair<double, int>> part;  // (class-c cost of the tile, tile)
+    for (const int t : mine) {
+      double cc = 0;
+      for (int64_t q = tiles[(size_t)t].start; q < tiles[(size_t)t].start + tiles[(size_t)t].count; ++q)
+        if (cls_of(items[(size_t)q]) == c) cc += items[(size_t)q].fp;
+      if (cc > 0) part.push_back({cc, t});
+    }
+    std::stable_sort(part.begin(), part.end(), [](const std::pair<double, int>& u, const std::pair<double, int>& v) { return u.first > v.first; });
+    std::vector<double> ql(8, 0.0);
+    std::vector<std::vector<int>> queue(8);
+    for (const auto& pt : part) {
+      const int qd = (int)(std::min_element(ql.begin(), ql.end()) - ql.begin());
+      ql[(size_t)qd] += pt.first;
+      queue[(size_t)qd].push_back(pt.second);
+    }
+    for (int qd = 0; qd < 8; ++qd) {
+      p->qstart[8 * c + qd] = (int64_t)p->pairs.size() / 2;
+      for (const int t : queue[(size_t)qd])
+        for (int64_t q = tiles[(size_t)t].start; q < tiles[(size_t)t].start + tiles[(size_t)t].count; ++q) {
+          const Item& it = items[(size_t)q];
+          if (cls_of(it) != c) continue;
+          p->groups.push_back((int32_t)(p->pairs.size() / 2));
+          p->groups.push_back(1);
+          p->pairs.push_back(it.i);
+          p->pairs.push_back(it.j);
+          if (c == 1) p->second.pairs += 1, p->second.flops += it.f, p->second.padded_flops += it.fp, p->second.bytes += it.by;
+        }
+    }
+  }
+  const int64_t np = (int64_t)p->pairs.size() / 2;
+  p->qstart[16] = np;
+  p->group = 1;
+  p->n_first = p->qstart[8];  // == np when there is one class
+  p->total_pairs = (int64_t)items.size();
+  p->max_per_rank = *std::max_element(per_rank.begin(), per_rank.end());
+  p->stats.pairs = np;
+  p->stats.flops = flops, p->stats.padded_flops = padded, p->stats.bytes = bytes;
+  p->fit_two = padded > 0 ? fit_two / padded : 1.0;
+}
+
 extern "C" int qk_plan_create(int32_t n_sites, int32_t nx, const int32_t* x_dims, int32_t ny, const int32_t* y_dims,
                               uint32_t flags, int32_t world_size, int32_t rank, int32_t block, qk_plan** out) {
   if (!out || !x_dims || n_sites <= 0 || nx <= 0) return fail(QK_EINVAL, "qk_plan_create: bad argument");
@@ -169,7 +362,8 @@ extern "C" int qk_plan_create(int32_t n_sites, int32_t nx, const int32_t* x_dims
   } else if (!y_dims || ny <= 0)
     return fail(QK_EINVAL, "qk_plan_create: y_dims required unless symmetric");
   if (world_size <= 0 || rank < 0 || rank >= world_size) return fail(QK_EINVAL, "qk_plan_create: bad rank %d/%d", rank, world_size);
-  if (block <= 0) block = std::max(nx, ny);  // one tile: the whole pair list in cost order (locality blocks measured no gain)
+  const int block_arg = block;
+  if (block <= 0) block = std::max(nx, ny);  // flat list (QK_PLAN_XCD=0): the whole pair list in cost order
   qk_plan* p = new (std::nothrow) qk_plan;
   if (!p) return fail(QK_ENOMEM, "qk_plan_create: out of memory");
   p->n_sites = n_sites, p->nx = nx, p->ny = ny, p->symmetric = sym, p->world = world_size, p->rank = rank;
@@ -238,6 +432,16 @@ extern "C" int qk_plan_create(int32_t n_sites, int32_t nx, const int32_t* x_dims
     p->stats.flops = flops, p->stats.padded_flops = padded, p->stats.bytes = bytes;
     *out = p;
     return QK_OK;
+  }
+  {
+    const char* e = std::getenv("QK_PLAN_XCD");
+    if (block_arg <= 0 && !(e && std::atoi(e) == 0)) {
+      int T = 8;
+      if (const char* te = std::getenv("QK_PLAN_TILE")) T = std::max(1, std::min(64, std::atoi(te)));
+      plan_tiled(p, n_sites, nx, x_dims, ny, y_dims, sym, orient, world_size, rank, T);
+      *out = p;
+      return QK_OK;
+    }
   }
   std::vector<Item> tile;
   const int stride = n_sites + 1;
@@ -345,6 +549,7 @@ extern "C" int qk_plan_create(int32_t n_sites, int32_t nx, const int32_t* x_dims
   p->stats.pairs = (int64_t)p->pairs.size() / 2;
   p->stats.flops = flops, p->stats.padded_flops = padded, p->stats.bytes = bytes;
   p->fit_two = padded > 0 ? fit_two / padded : 1.0;
+  p->nq = 1;  // the flat list: one queue per launch
   *out = p;
   return QK_OK;
 }
@@ -361,6 +566,12 @@ extern "C" int64_t qk_plan_total_pairs(const qk_plan* p) { return p ? p->total_p
 extern "C" int64_t qk_plan_max_pairs_per_rank(const qk_plan* p) { return p ? p->max_per_rank : 0; }
 extern "C" const int32_t* qk_plan_pairs(const qk_plan* p) { return p ? p->pairs.data() : nullptr; }
 extern "C" int64_t qk_plan_first_run(const qk_plan* p) { return p ? (p->n_first > 0 ? p->n_first : (int64_t)p->pairs.size() / 2) : 0; }
+extern "C" int qk_plan_queues(const qk_plan* p, int64_t* qstart) {
+  if (!p) return 0;
+  if (qstart)
+    for (int s = 0; s <= QK_NQ_MAX; ++s) qstart[s] = p->nq > 1 ? p->qstart[s] : (s == 0 ? 0 : (int64_t)p->pairs.size() / 2);
+  return p->nq;
+}
 extern "C" int qk_plan_stats(const qk_plan* p, qk_stats* out) {
   if (!p || !out) return fail(QK_EINVAL, "qk_plan_stats: null argument");
   *out = p->stats;
@@ -443,7 +654,7 @@ static int ctx_init(qk_ctx* c, int device_id, int num_cus) {
   HIP_TRY(hipEventCreate(&c->ev0));
   HIP_TRY(hipEventCreate(&c->ev1));
   HIP_TRY(hipEventCreate(&c->ev_mid));
-  HIP_TRY(hipMalloc(&c->counter, 2 * sizeof(unsigned long long)));  // one work queue per launch of a split sweep
+  HIP_TRY(hipMalloc(&c->counter, (QK_NQ_MAX * QK_QSTRIDE + 8) * sizeof(unsigned long long)));  // queue heads (8 per launch of a split sweep), tail clocks
   HIP_TRY(hipMalloc(&c->prof, 8 * sizeof(unsigned long long)));
   HIP_TRY(hipMemset(c->prof, 0, 8 * sizeof(unsigned long long)));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(qk_sweep_ring_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
@@ -508,6 +719,7 @@ extern "C" int qk_mps_set_create(qk_ctx* c, int32_t n_states, int32_t n_sites, c
                                  const double* const* site_tensors, int32_t layout, qk_mps_set** out) {
   if (!c || !out || !bond_dims || !site_tensors) return fail(QK_EINVAL, "qk_mps_set_create: null argument");
   if (n_states <= 0 || n_sites <= 0) return fail(QK_EINVAL, "qk_mps_set_create: empty set (%d states, %d sites)", n_states, n_sites);
+  QkRangeGuard range_("qk:upload");
   HIP_TRY(hipSetDevice(c->device));
   const int stride = n_sites + 1;
   std::vector<int32_t> pad((size_t)n_states * stride);
@@ -586,7 +798,7 @@ extern "C" int qk_mps_set_info(const qk_mps_set* m, int32_t* n_states, int32_t* 
   if (n_states) *n_states = m->n_states;
   if (n_sites) *n_sites = m->n_sites;
   if (max_padded_bond) *max_padded_bond = m->max_pad;
-  if (device_bytes) *device_bytes = m->bytes;
+  if (device_bytes) *device_bytes = m->bytes * (m->d_il ? 2 : 1);  // the interleaved twin the fused / wave2 sweeps make on first use counts
   return QK_OK;
 }
 
@@ -694,13 +906,16 @@ extern "C" int qk_mps_set_to_f32(qk_ctx* c, const qk_mps_set* src, qk_mps_set** 
 // the interleaved complex128 image of a set, made once on the device from the split planes
 static int ensure_interleaved(qk_ctx* c, qk_mps_set* m) {
   if (m->d_il) return QK_OK;
-  HIP_TRY(hipMalloc(&m->d_il, (size_t)m->bytes));
+  DevBuf il;  // published only after the conversion has been launched without error (released otherwise)
+  HIP_TRY(il.alloc((size_t)m->bytes));
   const long long nt = (long long)m->n_states * m->n_sites;
   const dim3 grid((unsigned)std::min<long long>(nt, 64ll * c->num_cus));
-  if (m->precision == 64) qk_interleave_kernel<double><<<grid, dim3(256), 0, c->stream>>>(m->d_data, m->d_il, m->d_dims, m->d_offs, m->n_sites, nt);
+  if (m->precision == 64) qk_interleave_kernel<double><<<grid, dim3(256), 0, c->stream>>>(m->d_data, il.as<double>(), m->d_dims, m->d_offs, m->n_sites, nt);
   else  // complex64 image of an fp32 set (same offsets, counted in floats)
-    qk_interleave_kernel<float><<<grid, dim3(256), 0, c->stream>>>(reinterpret_cast<const float*>(m->d_data), reinterpret_cast<float*>(m->d_il), m->d_dims, m->d_offs, m->n_sites, nt);
+    qk_interleave_kernel<float><<<grid, dim3(256), 0, c->stream>>>(reinterpret_cast<const float*>(m->d_data), il.as<float>(), m->d_dims, m->d_offs, m->n_sites, nt);
   HIP_TRY(hipGetLastError());
+  m->d_il = il.as<double>();
+  il.p = nullptr;
   return QK_OK;
 }
 
@@ -730,6 +945,7 @@ extern "C" int qk_gram_values(qk_ctx* c, const qk_mps_set* xs, const qk_mps_set*
   if (xs->ctx != c || ys->ctx != c) return fail(QK_EINVAL, "qk_gram_values: sets belong to another context");
   if (xs->n_sites != ys->n_sites || xs->n_sites != plan->n_sites) return fail(QK_EINVAL, "qk_gram_values: site counts differ (%d, %d, plan %d)", xs->n_sites, ys->n_sites, plan->n_sites);
   if (plan->nx != xs->n_states || plan->ny != ys->n_states) return fail(QK_EINVAL, "qk_gram_values: plan is for %dx%d states, sets hold %dx%d", plan->nx, plan->ny, xs->n_states, ys->n_states);
+  QkRangeGuard range_("qk:sweep");
   HIP_TRY(hipSetDevice(c->device));
   const long long np = (long long)plan->pairs.size() / 2;
   c->last = plan->stats;
@@ -792,13 +1008,21 @@ extern "C" int qk_gram_values(qk_ctx* c, const qk_mps_set* xs, const qk_mps_set*
   a.values = values_dev, a.z = z_dev;
   a.scratch = c->scratch, a.x_plane = x_plane, a.t_plane = t_plane;
   a.counter = c->counter;
+  a.nq = 1;  // kernels with XCD queues (site-fused, wave2) get the plan's queues below
+  for (int s_ = 0; s_ <= QK_NQ_MAX; ++s_) a.qstart[s_] = plan->nq > 1 ? plan->qstart[s_] : (s_ == 0 ? 0 : np);
+  // device clocks for the tail accounting, behind the queue heads: launch 1 uses [0] [1] [4], launch 2 [2] [3] [6]
+  unsigned long long* const tail = c->counter + QK_NQ_MAX * QK_QSTRIDE;
+  a.tail = tail;
   a.prof = c->prof;
   a.debug_flags = 0, a.prio_mode = 0;
 #ifdef QK_LAB  // timing experiments of the lab kernels (they give wrong results by construction): libqklab.so only
   if (const char* v = std::getenv("QK_DEBUG_FLAGS")) a.debug_flags = std::atoi(v);
   if (const char* v = std::getenv("QK_PRIO")) a.prio_mode = std::atoi(v);
 #endif
-  HIP_TRY(hipMemsetAsync(c->counter, 0, 2 * sizeof(unsigned long long), c->stream));
+  HIP_TRY(hipMemsetAsync(c->counter, 0, (QK_NQ_MAX * QK_QSTRIDE + 8) * sizeof(unsigned long long), c->stream));
+  HIP_TRY(hipMemsetAsync(tail, 0xFF, 4 * sizeof(unsigned long long), c->stream));  // the four minima
+  c->last.queues = 1, c->last.tail_frac = c->last.second_tail_frac = 0;
+  c->tail_pending = false;
   HIP_TRY(hipEventRecord(c->ev0, c->stream));
   int launched_grid = grid;
   // per-pair site metadata in LDS behind the three ring slots: 4 (n+1) ints + 2 n int64 (+ alignment)
@@ -828,6 +1052,7 @@ extern "C" int qk_gram_values(qk_ctx* c, const qk_mps_set* xs, const qk_mps_set*
     a.xdata = xs->d_il, a.ydata = ys->d_il;
     HIP_TRY(hipEventRecord(c->ev0, c->stream));  // the conversion above is not part of the sweep
     const int wgrid = (int)std::min<long long>(np, 8ll * c->num_cus);
+    a.nq = plan->nq, c->last.queues = plan->nq > 1 ? 8 : 1, c->tail_pending = true;
     if (f32) qk_sweep_wave2_kernel<3, float><<<dim3(wgrid), dim3(64), 0, c->stream>>>(a);  // complex64 storage, fp64 arithmetic
     else if (c->wave2_ring) qk_sweep_wave2_kernel<3, double><<<dim3(wgrid), dim3(64), 0, c->stream>>>(a);
     else qk_sweep_wave2_kernel<0, double><<<dim3(wgrid), dim3(64), 0, c->stream>>>(a);
@@ -847,6 +1072,7 @@ extern "C" int qk_gram_values(qk_ctx* c, const qk_mps_set* xs, const qk_mps_set*
     a.xdata = xs->d_il, a.ydata = ys->d_il;
     a.x_plane = (long long)xs->max_pad * ys->max_pad;  // complex elements per global X buffer (two per workgroup)
     HIP_TRY(hipEventRecord(c->ev0, c->stream));        // the conversion above is not part of the sweep
+    a.nq = plan->nq, c->last.queues = plan->nq > 1 ? 8 : 1, c->tail_pending = true;
     // the dual form (pairs of tiles per wave: half the A and X fragments per matrix instruction) against single tiles, same box:
     // uniform bonds 48 / 64 / 96 / 128 / 256: +2 / +4 / +7 / +12 / +19 %; first run of the headline set's split sweep: 255 against 264 ms
     if (fused_two) QKF_KERNEL_TWO<<<dim3(grid), dim3(64 * QKF_TWO_NW), lds_fused, c->stream>>>(a);
@@ -858,7 +1084,11 @@ extern "C" int qk_gram_values(qk_ctx* c, const qk_mps_set* xs, const qk_mps_set*
       a1.npairs = plan->n_first;
       a2.pairs = a.pairs + 2 * plan->n_first, a2.npairs = np - plan->n_first;
       a2.values = a.values + plan->n_first, a2.z = a.z ? a.z + 2 * plan->n_first : nullptr;
-      a2.counter = c->counter + 1;
+      a2.counter = c->counter + 8 * QK_QSTRIDE, a2.tail = tail + 2;
+      if (plan->nq > 1) {  // 8 queues per run
+        a1.nq = a2.nq = 8;
+        for (int s_ = 0; s_ <= 8; ++s_) a2.qstart[s_] = plan->qstart[8 + s_] - plan->n_first;
+      }
       if (dual) QKF_KERNEL_DUAL<<<dim3((unsigned)std::min<long long>(a1.npairs, c->num_cus)), dim3(64 * QKF_DUAL_NW), lds_fused, c->stream>>>(a1);
       else QKF_KERNEL_ONE<<<dim3((unsigned)std::min<long long>(a1.npairs, c->num_cus)), dim3(64 * QKF_ONE_NW), lds_fused, c->stream>>>(a1);
       HIP_TRY(hipEventRecord(c->ev_mid, c->stream));
@@ -909,6 +1139,7 @@ extern "C" int qk_gram_values_host(qk_ctx* c, const qk_mps_set* xs, const qk_mps
 extern "C" int qk_scatter(qk_ctx* c, const int32_t* pairs_dev, const double* values_dev, int64_t n, double* k_dev, int64_t ld, int32_t mirror) {
   if (!c || !pairs_dev || !values_dev || !k_dev) return fail(QK_EINVAL, "qk_scatter: null argument");
   if (n <= 0) return QK_OK;
+  QkRangeGuard range_("qk:scatter");
   HIP_TRY(hipSetDevice(c->device));
   const int bs = 256;
   hipLaunchKernelGGL(qk_scatter_kernel, dim3((unsigned)((n + bs - 1) / bs)), dim3(bs), 0, c->stream, pairs_dev, values_dev, (long long)n, k_dev, (long long)ld, (int)mirror);
@@ -944,6 +1175,16 @@ extern "C" int qk_get_stats(qk_ctx* c, qk_stats* out) {
     float ms = 0;
     HIP_TRY(hipEventElapsedTime(&ms, c->ev0, c->ev1));
     c->last.kernel_ms = ms;
+    if (c->tail_pending) {  // device clocks of the launch(es): share of the duration during which the chip was draining
+      unsigned long long t[8];
+      HIP_TRY(hipMemcpy(t, c->counter + QK_NQ_MAX * QK_QSTRIDE, sizeof t, hipMemcpyDeviceToHost));
+      auto frac = [](const unsigned long long start, const unsigned long long first_exit, const unsigned long long last_exit) {
+        return (last_exit > start && first_exit <= last_exit && first_exit >= start) ? (double)(last_exit - first_exit) / (double)(last_exit - start) : 0.0;
+      };
+      c->last.tail_frac = frac(t[0], t[1], t[4]);
+      if (c->split_pending) c->last.second_tail_frac = frac(t[2], t[3], t[6]);
+      c->tail_pending = false;
+    }
     if (c->split_pending) {
       HIP_TRY(hipEventElapsedTime(&ms, c->ev_mid, c->ev1));
       c->last.second_ms = ms;

@@ -128,7 +128,11 @@ def exchange_sets(comm, ctx, local, lo: int, total: int, force_collective: bool 
         use_nccl = False
     if use_nccl:
         dev = torch.device("cuda", ctx.device_id)
-        send = torch.zeros(mx, dtype=torch.float64, device=dev)
+        # torch.empty, not zeros: a fill would run on torch's current stream while copy_image copies on the context's own
+        # (non-blocking) stream -- the two are not ordered, so zeros could land on top of the image.  Nothing addresses the
+        # bytes behind the image (the offsets end inside it); copy_image returns after its copy has completed.
+        send = torch.empty(mx, dtype=torch.float64, device=dev)
+        torch.cuda.current_stream(dev).synchronize()  # nothing of torch's is pending on the buffer when the context's stream writes it
         if local is not None:
             local.copy_image(send.data_ptr(), mx)
         recv = torch.empty(size * mx, dtype=torch.float64, device=dev)
@@ -144,6 +148,10 @@ def exchange_sets(comm, ctx, local, lo: int, total: int, force_collective: bool 
             parts = [mine]
         elif hasattr(comm, "allgather_array") and comm.backend() != "nccl":
             parts = comm.allgather_array(mine)
+        elif hasattr(comm, "Allgather"):  # mpi4py: the buffer interface (no pickling; counts beyond 2^31 bytes are fine as doubles)
+            joined_buf = np.empty(size * mx, dtype=np.float64)
+            comm.Allgather(mine, joined_buf)
+            parts = [joined_buf]
         else:
             parts = comm_allgather(comm, mine)
         joined = np.concatenate(parts)

@@ -42,7 +42,9 @@ class QkStats(C.Structure):
         ("second_bytes", C.c_double),
         ("second_ms", C.c_double),
         ("second_kernel", C.c_int32),
-        ("reserved", C.c_int32),
+        ("queues", C.c_int32),
+        ("tail_frac", C.c_double),
+        ("second_tail_frac", C.c_double),
     ]
 
     def as_dict(self):
@@ -79,6 +81,7 @@ _SIGNATURES = [
     ("qk_plan_pairs", _P, [_P]),
     ("qk_plan_stats", C.c_int, [_P, C.POINTER(QkStats)]),
     ("qk_plan_first_run", C.c_int64, [_P]),
+    ("qk_plan_queues", C.c_int, [_P, _P]),
     ("qk_gram_values", C.c_int, [_P, _P, _P, _P, _P, _P]),
     ("qk_gram_values_host", C.c_int, [_P, _P, _P, _P, _P, _P]),
     ("qk_scatter", C.c_int, [_P, _P, _P, C.c_int64, _P, C.c_int64, C.c_int32]),
@@ -93,6 +96,16 @@ _SIGNATURES = [
     ("qk_built_destroy", C.c_int, [_P]),
     ("qk_mps_set_from_built", C.c_int, [_P, _P, C.POINTER(_P)]),
     ("qk_debug_jacobi", C.c_int, [_P, C.c_int32, C.c_int32, _P, _P, _P, _P]),
+    ("qk_range_push", C.c_int, [C.c_char_p]),
+    ("qk_range_pop", C.c_int, []),
+    ("qk_comm_init_all", C.c_int, [C.c_int32, _P, C.POINTER(_P)]),
+    ("qk_comm_destroy", C.c_int, [_P]),
+    ("qk_comm_size", C.c_int32, [_P]),
+    ("qk_comm_ctx", _P, [_P, C.c_int32]),
+    ("qk_mps_set_allgather", C.c_int, [_P, _P, _P, C.c_int32, _P]),
+    ("qk_gram_sharded", C.c_int, [_P, _P, _P, _P, C.c_int64]),
+    ("qk_comm_device_gram", C.c_int, [_P, C.c_int32, C.POINTER(_P)]),
+    ("qk_comm_stats", C.c_int, [_P, C.c_int32, C.POINTER(QkStats), C.POINTER(C.c_double)]),
 ]
 EXPORTED_SYMBOLS = [s[0] for s in _SIGNATURES]
 # entry points of csrc/qk_lab.h: only the lab library (libqklab.so, loaded by tools/ via use_lab_library()) has them
@@ -233,6 +246,12 @@ class Plan:
     def first_run(self) -> int:
         """Pairs [first_run, num_pairs) are the run the site-fused sweep takes with its two-workgroups-per-CU shape."""
         return int(lib().qk_plan_first_run(self._h))
+
+    def queues(self):
+        """(number of device work queues, qstart[17]): queue s = pairs [qstart[s], qstart[s+1]) -- 8 per run of the list, one
+        per XCD (include/qkgram.h: qk_plan_queues); 1 queue = the flat cost-ordered list."""
+        qs = np.zeros(17, dtype=np.int64)
+        return int(lib().qk_plan_queues(self._h, qs.ctypes.data)), qs
 
     def stats(self) -> dict:
         st = QkStats()
@@ -559,7 +578,84 @@ class Context:
 
     def close(self):
         if self._h:
-            lib().qk_ctx_destroy(self._h)
+            if not getattr(self, "_borrowed", False):  # a communicator's contexts die with the communicator
+                lib().qk_ctx_destroy(self._h)
+            self._h = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+
+class Comm:
+    """The multi-GPU part of the C ABI (``qk_comm_*``): ONE process drives k MI355X of a node; RCCL over xGMI is reached
+    inside the library (``ncclCommInitAll`` / ``ncclAllGather``), not through torch.  What the reference does with an
+    mpi4py communicator and one process per GPU (/root/reference/gpu_backend/kernel_state_ansatz.py:149-199, 415-428)."""
+
+    def __init__(self, n_devices: int | None = None, device_ids=None):
+        if device_ids is not None:
+            ids = np.ascontiguousarray(device_ids, dtype=np.int32)
+            n_devices = int(ids.shape[0])
+        else:
+            ids = None
+            n_devices = int(n_devices or device_count())
+        h = _P()
+        _check(lib().qk_comm_init_all(n_devices, None if ids is None else ids.ctypes.data, C.byref(h)), "qk_comm_init_all")
+        self._h, self.size = h, int(lib().qk_comm_size(h))
+        self._ctx = []
+        for r in range(self.size):
+            c = Context.__new__(Context)
+            c._h, c.device_id, c._borrowed = _P(lib().qk_comm_ctx(h, r)), int(ids[r]) if ids is not None else r, True
+            self._ctx.append(c)
+
+    def ctx(self, rank: int) -> "Context":
+        return self._ctx[rank]
+
+    def allgather_sets(self, local, lo, total: int):
+        """``local[r]``: the MpsSet of the states ``[lo[r], lo[r] + len(local[r]))`` on rank r's context (``None`` = empty
+        share).  ONE all-gather of the packed images; returns the whole set on every device."""
+        hs = (_P * self.size)(*[(m.handle if m is not None else None) for m in local])
+        lo_a = np.ascontiguousarray(lo, dtype=np.int32)
+        out = (_P * self.size)()
+        _check(lib().qk_mps_set_allgather(self._h, hs, lo_a.ctypes.data, int(total), out), "qk_mps_set_allgather")
+        n_sites = next(m for m in local if m is not None).dims.shape[1] - 1
+        dims = np.zeros((total, n_sites + 1), dtype=np.int32)
+        for m, l0 in zip(local, lo):
+            if m is not None:
+                dims[l0 : l0 + len(m)] = m.dims
+        return [MpsSet(self._ctx[r], _P(out[r]), dims.copy()) for r in range(self.size)]
+
+    def gram(self, xsets, ysets=None) -> np.ndarray:
+        """The sharded Gram: one sweep launch per device, ONE all-gather of the packed values, a scatter per device;
+        returns rank 0's dense matrix (rows = Y, cols = X)."""
+        nx = len(xsets[0])
+        ny = nx if ysets is None else len(ysets[0])
+        xs = (_P * self.size)(*[m.handle for m in xsets])
+        ys = None if ysets is None else (_P * self.size)(*[m.handle for m in ysets])
+        out = np.zeros((ny, nx), dtype=np.float64)
+        _check(lib().qk_gram_sharded(self._h, xs, ys, out.ctypes.data, nx), "qk_gram_sharded")
+        return out
+
+    def device_gram_ptr(self, rank: int) -> int:
+        p = _P()
+        _check(lib().qk_comm_device_gram(self._h, rank, C.byref(p)), "qk_comm_device_gram")
+        return int(p.value or 0)
+
+    def stats(self, rank: int = 0):
+        st, ms = QkStats(), C.c_double()
+        _check(lib().qk_comm_stats(self._h, rank, C.byref(st), C.byref(ms)), "qk_comm_stats")
+        d = st.as_dict()
+        d["kernel_name"] = lib().qk_kernel_name(st.kernel, st.precision).decode()
+        d["allgather_ms"] = ms.value
+        return d
+
+    def close(self):
+        if self._h:
+            for c in self._ctx:
+                c._h = None
+            lib().qk_comm_destroy(self._h)
             self._h = None
 
     def __enter__(self):

@@ -432,6 +432,49 @@ def test_c_abi_example_runs(gpu_ctx, tmp_path):
     r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "max |K - closed form|" in r.stdout
+    assert "sharded over" in r.stdout  # the multi-GPU entry points (qk_comm_*), here a communicator of one rank
+
+
+def test_c_abi_communicator_sharded_gram(gpu_ctx):
+    """The multi-GPU part of the C ABI on a one-device communicator: shares -> qk_mps_set_allgather (ncclAllGather of the
+    packed images) -> qk_gram_sharded (sweep, ncclAllGather of the values, scatter) against the single-context Gram and
+    the oracle; rectangular Gram; plans are reused when the same sets come back; bad input fails loudly."""
+    import qml_cutensornet_amd as Q
+    from oracle import restatement as R
+    from qml_cutensornet_amd import engine
+
+    rng = np.random.default_rng(23)
+    n = 18
+    xs = [Q.random_mps(n, _ragged_profile(rng, n, c), rng) for c in (70, 33, 9, 120, 48, 16, 80)]
+    ys = [Q.random_mps(n, _ragged_profile(rng, n, c), rng) for c in (40, 90, 12)]
+    K_ref = R.gram_from_mps([m.tensors for m in xs])
+    Kxy_ref = R.gram_from_mps([m.tensors for m in xs], [m.tensors for m in ys])
+    with engine.Comm(1) as comm:
+        assert comm.size == 1
+        c0 = comm.ctx(0)
+        share = c0.upload(xs)
+        full = comm.allgather_sets([share], [0], len(xs))
+        assert np.array_equal(full[0].dims, share.dims)
+        n_img, _, _, offs = full[0].image()
+        assert n_img >= share.image()[0] and np.array_equal(offs, share.image()[3])
+        K = comm.gram(full)
+        st = comm.stats(0)
+        assert st["pairs"] == len(xs) * (len(xs) + 1) // 2 and st["kernel_ms"] > 0 and st["allgather_ms"] >= 0
+        assert np.abs(K - K_ref).max() < TOL and np.array_equal(K, K.T)
+        assert np.abs(K - gpu_ctx.gram(gpu_ctx.upload(xs))).max() < 1e-13
+        K2 = comm.gram(full)  # same sets: the cached plans and buffers
+        assert np.abs(K2 - K).max() < 1e-14
+        ysets = [c0.upload(ys)]
+        Kxy = comm.gram(full, ysets)
+        assert Kxy.shape == (len(ys), len(xs)) and np.abs(Kxy - Kxy_ref).max() < TOL
+        with pytest.raises(engine.QkError, match="belongs to no share"):
+            comm.allgather_sets([share], [0], len(xs) + 1)
+        with pytest.raises(engine.QkError):
+            comm.allgather_sets([gpu_ctx.upload(xs)], [0], len(xs))  # a set of another context
+        for m in (share, full[0], ysets[0]):
+            m.close()
+    with pytest.raises(engine.QkError):
+        engine.Comm(device_ids=[0, 0])  # one rank per GPU
 
 
 def test_large_bonds(gpu_ctx):

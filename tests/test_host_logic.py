@@ -135,6 +135,8 @@ def test_no_gpu_means_loud_failure(built):
         pytest.skip("a GPU is present")
     with pytest.raises(engine.QkError, match="no CPU fallback"):
         engine.Context(0)
+    with pytest.raises(engine.QkError, match="no CPU fallback"):
+        engine.Comm(1)  # the multi-GPU entry points fail the same way
     from qml_cutensornet_amd.dist import SingleComm
     from qml_cutensornet_amd.gpu_backend.kernel_state_ansatz import build_kernel_matrix
     import qml_cutensornet_amd as Q
@@ -336,6 +338,57 @@ def test_default_plan_balances_rank_shares(built):
             costs.append(p.stats()["padded_flops"])
             p.close()
         assert max(costs) / min(costs) < 1.01, (world, costs)
+
+
+@pytest.mark.parametrize("world", [1, 3])
+@pytest.mark.parametrize("symmetric", [True, False])
+def test_tiled_plan_xcd_queues(built, monkeypatch, world, symmetric):
+    """Default plan = XCD-aware work queues: every pair exactly once over the ranks, 8 contiguous queues per run, the pairs
+    of a queue come tile by tile (a tile = at most T x-states times T y-states), the flat list (QK_PLAN_XCD=0) holds the same
+    pairs with the same algorithmic work, and the rank shares are level."""
+    from qml_cutensornet_amd import engine
+
+    rng = np.random.default_rng(17 + world)
+    nx, ny, n, T = 53, 29, 14, 4
+    xd = np.ones((nx, n + 1), dtype=np.int32)
+    yd = np.ones((ny, n + 1), dtype=np.int32)
+    xd[:, 1:-1] = rng.lognormal(3.6, 0.7, size=(nx, n - 1)).astype(np.int32).clip(1, 200)
+    yd[:, 1:-1] = rng.lognormal(3.6, 0.7, size=(ny, n - 1)).astype(np.int32).clip(1, 200)
+    monkeypatch.setenv("QK_PLAN_TILE", str(T))
+    seen, flops, costs = set(), 0.0, []
+    for r in range(world):
+        p = engine.Plan(xd, None if symmetric else yd, world, r)
+        pr = p.pairs()
+        nq, qs = p.queues()
+        assert nq == 16 and qs[0] == 0 and qs[16] == len(pr) and (np.diff(qs) >= 0).all() and qs[8] == p.first_run
+        for s in range(16):
+            q = pr[qs[s] : qs[s + 1]]
+            # tile by tile: cut the queue where the set of states would outgrow a tile; every piece is a tile
+            k = 0
+            while k < len(q):
+                xs, ys, e = set(), set(), k
+                while e < len(q) and len(xs | {q[e, 0]} | (ys | {q[e, 1]} if symmetric else set())) <= 2 * T and (symmetric or (len(xs | {q[e, 0]}) <= T and len(ys | {q[e, 1]}) <= T)):
+                    xs.add(q[e, 0]), ys.add(q[e, 1])
+                    e += 1
+                assert e > k
+                k = e
+        for i, j in pr.tolist():
+            key = (min(i, j), max(i, j)) if symmetric else (i, j)
+            assert key not in seen
+            seen.add(key)
+        st = p.stats()
+        flops += st["flops"]
+        costs.append(st["padded_flops"])
+        p.close()
+    assert len(seen) == (nx * (nx + 1) // 2 if symmetric else nx * ny)
+    monkeypatch.setenv("QK_PLAN_XCD", "0")
+    flat = engine.Plan(xd, None if symmetric else yd)
+    assert flat.queues()[0] == 1
+    assert {((min(i, j), max(i, j)) if symmetric else (i, j)) for i, j in flat.pairs().tolist()} == seen
+    assert flops == pytest.approx(flat.stats()["flops"], rel=1e-12)
+    flat.close()
+    if world > 1:
+        assert max(costs) / min(costs) < 1.03
 
 
 def test_plan_work_model(built):

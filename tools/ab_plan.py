@@ -1,0 +1,60 @@
+#!/usr/bin/env python3
+"""A/B of planner settings on one config: flat cost-ordered list against XCD-aware tiled queues (QK_PLAN_XCD, QK_PLAN_TILE).
+    python tools/ab_plan.py [cfg4] [steps]     -> one line per setting: kernel ms (first / second launch), tail fractions"""
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+
+
+def main():
+    cfg = sys.argv[1] if len(sys.argv) > 1 else "cfg4"
+    steps = int(sys.argv[2]) if len(sys.argv) > 2 else 3
+    settings = [s.split(",") for s in (sys.argv[3:] or ["QK_PLAN_XCD=0", "QK_PLAN_TILE=8", "QK_PLAN_TILE=4", "QK_PLAN_TILE=16", "QK_PLAN_XCD=0"])]
+    import __graft_entry__ as graft
+
+    graft.build()
+    from qml_cutensornet_amd.builder_pool import default_workers
+
+    n, reps, d, npts = bench.CONFIGS[cfg]
+    gamma = 0.1 if cfg == "cfg5" else 1.0
+    states, binfo = bench.build_or_load_states(cfg, n, reps, d, gamma, npts, 5, 0, 1, default_workers())
+    print(f"states: {binfo}", flush=True)
+    import torch
+
+    from qml_cutensornet_amd import engine
+    from qml_cutensornet_amd.gram import GramJob
+
+    ctx = engine.Context(0)
+    xset = ctx.upload(states)
+    ref = None
+    for st in settings:
+        for k in ("QK_PLAN_XCD", "QK_PLAN_TILE", "QK_FUSED_SPLIT", "QK_PLAN_SPLIT"):
+            os.environ.pop(k, None)
+        for kv in st:
+            k, v = kv.split("=")
+            os.environ[k] = v
+        job = GramJob(ctx, xset, None, 1, 0)
+        K = job.run()
+        ms, ms2, tf, tf2 = [], [], [], []
+        for _ in range(steps):
+            job.enqueue()
+            torch.cuda.synchronize()
+            s_ = ctx.stats()
+            ms.append(s_["kernel_ms"]), ms2.append(s_["second_ms"]), tf.append(s_["tail_frac"]), tf2.append(s_["second_tail_frac"])
+        if ref is None:
+            ref = K
+        err = float(np.abs(K - ref).max())
+        print(f"{' '.join(st):32s} kernel {np.mean(ms):8.2f} ms (second launch {np.mean(ms2):7.2f}), tail {np.mean(tf):.4f} / {np.mean(tf2):.4f}, queues {s_['queues']}, {s_['kernel_name']}; max |K - K_first| {err:.2e}", flush=True)
+        job.close()
+    xset.close()
+    ctx.close()
+
+
+if __name__ == "__main__":
+    main()
