@@ -42,6 +42,7 @@ CONFIGS = {
 # fp64 matrix peak of MI355X: 256 CU x 4 SIMD x 32 flop/clk (v_mfma_f64_16x16x4: 2048 flop / 64 clk) x 2.4 GHz
 PEAK_F64_MFMA_TFLOPS = 256 * 4 * 32 * 2.4e9 / 1e12
 PEAK_F32_MFMA_TFLOPS = 256 * 4 * 64 * 2.4e9 / 1e12  # v_mfma_f32_16x16x4_f32: 64 flop/clk/SIMD (MI355X_MICROARCH.md)
+PEAK_HBM_BYTES = 8.0e12  # HBM3E, bytes/s (MI355X_MICROARCH.md)
 
 
 def log(rank, *a):
@@ -94,7 +95,62 @@ def build_or_load_states(name, n, reps, d, gamma, npts, seed, rank, world, worke
         fids += fd
         secs += s
     states = [Q.MPS(t, fd) for t, fd in zip(tensors, fids)]
-    return states, {"built_here": built, "build_wall_s": build_wall, "cpu_s_per_state": float(np.mean(secs))}
+    return states, {"built_here": built, "build_wall_s": build_wall, "cpu_s_per_state": float(np.mean(secs)), "ansatz": ansatz, "X": X}
+
+
+SWEEP_SOURCES = ("qk_fused.h", "qk_ring.h", "qk_device.h", "qkgram.hip")  # what a sweep kernel is compiled from
+
+
+def sweep_source_sha():
+    """Digest of the sweep kernels' sources: a committed PMC summary is quoted only while it describes THIS code."""
+    h = hashlib.sha256()
+    for f in SWEEP_SOURCES:
+        with open(os.path.join(ROOT, "qml-cutensornet_amd", "csrc", f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
+def quoted_traffic(cfg_name, kernels):
+    """HBM / fabric bytes per launch from the committed rocprofv3 --pmc summary of the same workload (PMC counters cannot be
+    read from inside this process): {kernel name: bytes}, the file, or (None, reason) when the summary is missing or was
+    taken on other sources."""
+    pmc_file = os.path.join(ROOT, "profiles", "r03", cfg_name, "pmc_summary.json")
+    if not os.path.exists(pmc_file):
+        return None, "no committed summary for this workload"
+    try:
+        pmc = json.load(open(pmc_file))
+    except ValueError:
+        return None, "unreadable summary"
+    if pmc.get("source_sha") != sweep_source_sha():
+        return None, f"stale: {os.path.relpath(pmc_file, ROOT)} was taken on sources {pmc.get('source_sha')}, this run is {sweep_source_sha()}"
+    out = {}
+    for k in kernels:
+        ent = next((v for name, v in pmc.get("kernels", {}).items() if k and k in name), None)
+        if ent is None or "traffic_bytes_per_launch" not in ent:
+            return None, f"the summary has no entry for {k}"
+        out[k] = ent["traffic_bytes_per_launch"]
+    return out, os.path.relpath(pmc_file, ROOT)
+
+
+def device_build_leg(ctx, ansatz, X, states, log_):
+    """The input producer on the device (SURVEY 8f N1): every circuit of the data set in ONE launch of the device builder, timed;
+    the Gram of the device-built set is returned so that the caller can compare it with the Gram of the host-built states
+    (the ones the timed steps run on).  Untimed region."""
+    circs = [ansatz.circuit_for_data(x) for x in X]
+    cap = int(os.environ.get("QK_BUILDER_MAX_BOND", "320"))
+    t0 = time.perf_counter()
+    try:
+        dset, info = ctx.build_mps_set(circs, max_bond=cap)
+    except Exception as exc:  # noqa: BLE001 - reported; the timed Gram does not depend on it
+        log_(f"device builder failed: {exc}")
+        return {"error": str(exc)}, None
+    wall = time.perf_counter() - t0
+    host_dims = np.array([m.bond_dims() for m in states])
+    differ = int((info["dims"] != host_dims).any(axis=1).sum())
+    K = ctx.gram(dset)
+    dset.close()
+    return {"device_kernel_s": info["kernel_ms"] / 1e3, "device_wall_s": wall, "max_bond_cap": cap, "states_whose_bonds_differ_from_host": differ,
+            "largest_bond_difference": int(np.abs(info["dims"] - host_dims).max())}, K
 
 
 def cpu_baseline(states, pairs, total_unique, npts, seconds, gpu_vals, threads):
@@ -226,22 +282,32 @@ def main():
         xset = x64.to_f32()
         x64.close()
         info = xset.info()
+    # the device MPS builder on the same circuits (rank 0, one GPU; QK_BENCH_DEVICE_BUILD=0 skips it): reported beside the host pool
+    dev_build, K_dev = None, None
+    if world == 1 and args.precision == "f64" and os.environ.get("QK_BENCH_DEVICE_BUILD", "1") != "0":
+        dev_build, K_dev = device_build_leg(ctx, binfo["ansatz"], binfo["X"], states, lambda t: log(rank, t))
+        if "error" not in dev_build:
+            log(rank, f"device MPS builder: {npts} states in {dev_build['device_kernel_s']:.2f} s (wall {dev_build['device_wall_s']:.2f} s); host pool: {binfo['cpu_s_per_state'] * npts / workers:.1f} s on {workers} workers")
     job = GramJob(ctx, xset, None, world, rank)
     my = job.work[rank]
     log(rank, f"uploaded {info['device_bytes'] / 2**30:.2f} GiB in {upload_s:.1f}s; rank 0 share: {my['pairs']} pairs, {my['flops'] / 1e12:.2f} TFlop algorithmic ({my['padded_flops'] / 1e12:.2f} padded)")
 
     host_K = torch.empty((npts, npts), dtype=torch.float64, pin_memory=True)
 
+    tails, second_ms = [], []  # per step: (tail share of the first launch, of the second); device time of the second launch of a split sweep
+
     def step():
+        engine.range_push("bench:step")
         K = job.enqueue()
         host_K.copy_(K, non_blocking=True)
         torch.cuda.current_stream().synchronize()
+        engine.range_pop()
         st_ = ctx.stats()
         second_ms.append(st_["second_ms"])
+        tails.append((st_["tail_frac"], st_["second_tail_frac"]))
         return st_["kernel_ms"]
 
     kernel_name = None
-    second_ms = []  # a split sweep (two launches, two shapes of the site-fused kernel): device time of the second launch
 
     for _ in range(args.warmup):
         step()
@@ -251,6 +317,7 @@ def main():
     t0 = time.perf_counter()
     kernel_ms = []
     second_ms.clear()
+    tails.clear()
     for _ in range(args.steps):
         kernel_ms.append(step())
     barrier()
@@ -269,7 +336,8 @@ def main():
     diag_err = float(np.abs(np.diag(Kh) - 1).max())
     sym_err = float(np.abs(Kh - Kh.T).max())
     # after the timed region: every rank's kernel time and a digest of its copy of K (all ranks hold the full matrix)
-    per_rank = [(kms, hashlib.sha1(np.ascontiguousarray(Kh).tobytes()).hexdigest(), my["padded_flops"] / 1e12)]
+    tail_all = float(np.mean([max(t) for t in tails])) if tails else 0.0
+    per_rank = [(kms, hashlib.sha1(np.ascontiguousarray(Kh).tobytes()).hexdigest(), my["padded_flops"] / 1e12, tail_all)]
     if world > 1:
         gathered = [None] * world
         dist.all_gather_object(gathered, per_rank[0])
@@ -278,29 +346,43 @@ def main():
     out = None
     if rank == 0:
         peak = PEAK_F64_MFMA_TFLOPS if args.precision == "f64" else PEAK_F32_MFMA_TFLOPS
-        # A split sweep is two launches (qk_stats.second_*): the roofline object is that of the DOMINANT one -- the first,
-        # `kernel_name`, with its own pairs' flops and its own duration -- and the second is listed beside it.
+        # A split sweep is two launches (qk_stats.second_*).  The roofline object prices the WHOLE sweep -- all pairs' algorithmic
+        # flops over the device time of both launches -- and lists each launch beside it.
         last = ctx.stats()
         s_ms = float(np.mean(second_ms)) if second_ms else 0.0
         split = last["second_kernel"] != 0 and s_ms > 0
         first_ms = kms - s_ms if split else kms
         first_flops = my["flops"] - (last["second_flops"] if split else 0.0)
-        achieved = first_flops / (first_ms * 1e-3) / 1e12 if first_ms > 0 else 0.0
-        second = None
+        bytes_scale = 1.0 if args.precision == "f64" else 0.5
+        launches = [{"kernel": kernel_name, "kernel_ms": first_ms, "pairs": int(my["pairs"] - (last["second_pairs"] if split else 0)), "algorithmic_tflop": first_flops / 1e12,
+                     "padded_4m_tflop": (my["padded_flops"] - (last["second_padded_flops"] if split else 0.0)) / 1e12,
+                     "algorithmic_gbytes": (my["bytes"] - (last["second_bytes"] if split else 0.0)) / 1e9 * bytes_scale,
+                     "achieved_tflops": first_flops / (first_ms * 1e-3) / 1e12 if first_ms > 0 else 0.0, "tail_frac": float(np.mean([t[0] for t in tails])) if tails else None}]
         if split:
-            a2 = last["second_flops"] / (s_ms * 1e-3) / 1e12
-            second = {"kernel": last["second_kernel_name"], "kernel_ms": s_ms, "pairs": int(last["second_pairs"]), "algorithmic_tflop_per_launch": last["second_flops"] / 1e12,
-                      "padded_4m_tflop_per_launch": last["second_padded_flops"] / 1e12, "achieved": a2, "frac": a2 / peak}
-        # HBM/fabric bytes per launch of the dominant kernel: PMC numbers cannot be collected from inside this
-        # process, so the committed rocprofv3 --pmc summary of the SAME workload (profiles/run_rocprof.sh) is quoted.
-        traffic = None
-        pmc_file = os.path.join(ROOT, "profiles", "r02", "pmc_summary.json")
-        if world == 1 and args.precision == "f64" and args.config == "cfg4" and args.gamma == 1.0 and not args.points and args.seed == 5 and os.path.exists(pmc_file):
-            try:
-                pmc = json.load(open(pmc_file))
-                traffic = pmc["derived"]["traffic_bytes_per_launch"] if kernel_name in pmc["kernel"] else None
-            except (KeyError, ValueError):
-                traffic = None
+            launches.append({"kernel": last["second_kernel_name"], "kernel_ms": s_ms, "pairs": int(last["second_pairs"]), "algorithmic_tflop": last["second_flops"] / 1e12,
+                             "padded_4m_tflop": last["second_padded_flops"] / 1e12, "algorithmic_gbytes": last["second_bytes"] / 1e9 * bytes_scale,
+                             "achieved_tflops": last["second_flops"] / (s_ms * 1e-3) / 1e12, "tail_frac": float(np.mean([t[1] for t in tails])) if tails else None})
+        for ln in launches:
+            ln["frac_of_mfma_peak"] = ln["achieved_tflops"] / peak
+            ln["hbm_algorithmic_tb_per_s"] = ln["algorithmic_gbytes"] / ln["kernel_ms"] if ln["kernel_ms"] > 0 else 0.0  # GB / ms = TB / s
+        whole_tflops = my["flops"] / (kms * 1e-3) / 1e12 if kms > 0 else 0.0
+        alg_bytes = my["bytes"] * bytes_scale
+        intensity = my["flops"] / alg_bytes if alg_bytes > 0 else 0.0  # algorithmic flop per byte
+        ridge = peak * 1e12 / PEAK_HBM_BYTES  # ~9.8 flop/B for fp64
+        bound = "mfma" if intensity >= ridge else "hbm"
+        # HBM / fabric bytes per sweep: quoted from the committed rocprofv3 --pmc summary of the SAME workload -- only while that summary
+        # was taken on the sources this run was built from (profiles/run_rocprof.sh records their digest)
+        traffic, traffic_src = None, "none (a reduced or non-default workload: no committed PMC summary describes it)"
+        cfg_dir = args.config if (world == 1 and args.precision == "f64" and not args.points and args.seed == 5 and args.gamma == (0.1 if args.config == "cfg5" else 1.0)) else None
+        if cfg_dir:
+            per_kernel, traffic_src = quoted_traffic(cfg_dir, [ln["kernel"] for ln in launches])
+            if per_kernel:
+                for ln in launches:
+                    ln["traffic_bytes"] = per_kernel[ln["kernel"]]
+                traffic = float(sum(per_kernel.values()))
+                traffic_src = f"quoted: {traffic_src} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of these kernels on this workload, gfx950 FETCH_SIZE correction as calibrated in profiles/r03/fetch_calibration.txt; source digest {sweep_source_sha()} matches)"
+            else:
+                traffic_src = f"none ({traffic_src})"
         out = {
             "metric": "Gram kernel entries/sec @ 60 qubits x 6 layers" if args.config == "cfg4" else f"Gram kernel entries/sec @ {n} qubits x {reps} layers",
             "value": npts * npts / (ms_per_step * 1e-3),
@@ -318,39 +400,45 @@ def main():
                 "workload": f"{args.config}: {n} qubits x {reps} layers, d={d}, gamma={args.gamma}, truncation 1e-16, {npts}x{npts} symmetric training Gram",
                 "unique_pairs": int(job.plan.total_pairs),
                 "overlaps_per_s": job.plan.total_pairs / (ms_per_step * 1e-3),
-                "parallelism": f"pairs in cost order dealt in serpentine order to {world} rank(s); one {'RCCL' if backend == 'nccl' else backend} all-gather of packed values",
+                "parallelism": f"states sorted by weight, Gram cut into 8 x 8 tiles of pairs, tiles dealt by cost to {world} rank(s) and, per rank, to 8 per-XCD work queues; one {'RCCL' if backend == 'nccl' else backend} all-gather of packed values",
                 "max_bond_mean": float(chi_max.mean()),
                 "max_bond_max": int(chi_max.max()),
                 "mps_gib": info["device_bytes"] / 2**30,
-                "mps_build_cpu_s_per_state": binfo["cpu_s_per_state"],
+                # the input producer (not part of the timed step): host pool (cpu-s per state, measured when built here) and the device builder
+                "mps_build": {"host_cpu_s_per_state": binfo["cpu_s_per_state"], "host_workers": workers, "host_pool_s": binfo["cpu_s_per_state"] * npts / workers,
+                              "host_pool_wall_s_this_run": binfo["build_wall_s"] if binfo["built_here"] == npts else None, **(dev_build or {})},
                 "diag_err": diag_err,
                 "sym_err": sym_err,
-                "rank_kernel_ms": [round(float(t), 3) for t, _, _ in per_rank],
-                "rank_padded_tflop": [round(float(f), 5) for _, _, f in per_rank],
-                "k_identical_on_all_ranks": len({h for _, h, _ in per_rank}) == 1,
+                "rank_kernel_ms": [round(float(t), 3) for t, _, _, _ in per_rank],
+                "rank_padded_tflop": [round(float(f), 5) for _, _, f, _ in per_rank],
+                "rank_tail_frac": [round(float(t), 5) for _, _, _, t in per_rank],
+                "k_identical_on_all_ranks": len({h for _, h, _, _ in per_rank}) == 1,
                 **({"f32_vs_f64_max_abs": float(np.abs(Kh - k64_ref).max()), "f32_vs_f64_median_abs": float(np.median(np.abs(Kh - k64_ref)))} if k64_ref is not None else {}),
+                **({"device_built_vs_host_built_gram_max_abs": float(np.abs(K_dev - Kh).max())} if K_dev is not None else {}),
             },
             "roofline": {
-                "bound": "mfma",  # fp64 matrix cores for f64, fp32 matrix cores for f32
-                "kernel": kernel_name,
-                "achieved": achieved,
-                "peak": peak,
-                "unit": "TFLOP/s",
-                "frac": achieved / peak,
+                # which roof binds THIS workload: algorithmic flop per algorithmic byte against the ridge of the dtype's matrix peak over HBM
+                "bound": bound,
+                "kernel": kernel_name if not split else f"{kernel_name} + {last['second_kernel_name']} (one sweep, two launches)",
+                "achieved": whole_tflops if bound == "mfma" else alg_bytes / (kms * 1e-3) / 1e9,
+                "peak": peak if bound == "mfma" else PEAK_HBM_BYTES / 1e9,
+                "unit": "TFLOP/s" if bound == "mfma" else "GB/s",
+                "frac": (whole_tflops / peak) if bound == "mfma" else (alg_bytes / (kms * 1e-3) / PEAK_HBM_BYTES),
                 "traffic": traffic,
-                "traffic_source": "profiles/r02/pmc_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this kernel on this workload, FETCH_SIZE x2 gfx950 correction), bytes per launch" if traffic else None,
-                # L2<->fabric rate those bytes imply at this run's kernel time (Infinity-Cache hits included; HBM peak ~8 TB/s)
-                "traffic_tb_per_s": (traffic / (first_ms * 1e-3) / 1e12) if (traffic and first_ms > 0) else None,
-                "kernel_ms": first_ms,
-                "algorithmic_tflop_per_launch": first_flops / 1e12,
-                # the same count with every bond rounded up to the 16-wide MFMA tile (four-product form); the sweep kernels
-                # issues 3/4 of the K-trimmed part of it (3M complex product): see profiles/r02/pmc_summary.json
-                "padded_4m_tflop_per_launch": (my["padded_flops"] - (last["second_padded_flops"] if split else 0.0)) / 1e12,
-                "algorithmic_gbytes_per_launch": (my["bytes"] - (last["second_bytes"] if split else 0.0)) / 1e9 * (1.0 if args.precision == "f64" else 0.5),
-                # both launches of a split sweep together: all pairs' flops over the whole device time
-                "whole_sweep": {"kernel_ms": kms, "algorithmic_tflop": my["flops"] / 1e12, "achieved": (my["flops"] / (kms * 1e-3) / 1e12) if kms > 0 else 0.0,
-                                "frac": (my["flops"] / (kms * 1e-3) / 1e12 / peak) if kms > 0 else 0.0},
-                "second_launch": second,
+                "traffic_source": traffic_src,
+                "traffic_tb_per_s": (traffic / (kms * 1e-3) / 1e12) if (traffic and kms > 0) else None,
+                "kernel_ms": kms,
+                "algorithmic_tflop_per_sweep": my["flops"] / 1e12,
+                "algorithmic_gbytes_per_sweep": alg_bytes / 1e9,
+                "algorithmic_flop_per_byte": intensity,
+                "ridge_flop_per_byte": ridge,
+                "frac_of_mfma_peak": whole_tflops / peak,
+                "frac_of_hbm_peak_algorithmic": alg_bytes / (kms * 1e-3) / PEAK_HBM_BYTES if kms > 0 else 0.0,
+                # the same flop count with every bond rounded up to the 16-wide MFMA tile (four-product form); the sweep kernels issue
+                # 3/4 of the K-trimmed part of it (3M complex product): see profiles/r03/<config>/pmc_summary.json
+                "padded_4m_tflop_per_sweep": my["padded_flops"] / 1e12,
+                "work_queues": int(last["queues"]),
+                "launches": launches,
             },
         }
         if world == 1 and args.cpu_seconds > 0:

@@ -292,6 +292,10 @@ int qk_selftest_mfma(qk_ctx* ctx);
 typedef struct qk_built qk_built;
 #define QK_BUILD_PARTIAL 1u /* a state that outgrows max_bond is dropped (its fidelity reads -1, it has no tensors: build it
                              * elsewhere) instead of failing the call; its workgroup stops at the offending gate        */
+#define QK_BUILD_TRUNCATE 2u /* max_bond is a bond CAP: at most max_bond singular values survive a gate (the `chi` of pytket-cutensornet's
+                             * Config, reference G:141-144, which the reference leaves unset); the weight it costs goes into the
+                             * state's fidelity like any other truncation.  Without it a state that needs more is an error (or, with
+                             * QK_BUILD_PARTIAL, dropped).                                                                          */
 int qk_build_mps(qk_ctx* ctx, int32_t n_states, int32_t n_qubits, int32_t n_ops, const int8_t* op, const int32_t* q0,
                  const double* alpha, double trunc_budget, double value_of_zero, int32_t max_bond, uint32_t flags,
                  qk_built** out);
@@ -306,6 +310,11 @@ int qk_built_destroy(qk_built* built);
 /* Diagnostic: the builder's Jacobi primitive on one host matrix a[p][q] (complex128 row-major, overwritten by A V);
  * v_out[q][q], sig_out[q] = column norms of A V, ord_out[q] = columns by decreasing norm.                          */
 int qk_debug_jacobi(qk_ctx* ctx, int32_t p, int32_t q, double* a_inout, double* v_out, double* sig_out, int32_t* ord_out);
+/* Diagnostic: the builder's factorisation for matrices beyond its LDS working set -- columns sorted, R by Gram-Schmidt, block
+ * Jacobi of R^H on the f64 matrix cores, W = A V -- on one host matrix a[p][q] (16 <= q <= 1024, p <= 1024): a <- W = A V
+ * (columns beyond the numerical rank are zero), v_out[q][q], sig_out[q] (0 beyond the rank), ord_out[q] as above;
+ * stats_out[6] (may be NULL) = sweeps, then device time in 100 MHz ticks: all, sort + copy, Gram-Schmidt, sweeps, V and W. */
+int qk_debug_jacobi_precond(qk_ctx* ctx, int32_t p, int32_t q, double* a_inout, double* v_out, double* sig_out, int32_t* ord_out, int32_t* stats_out);
 
 #ifdef __cplusplus
 }

@@ -18,7 +18,7 @@ from .mps import MPS, simulate
 _G = {}
 
 
-def _init(ansatz, fidelity):
+def _init(ansatz, fidelity, max_bond=None):
     for v in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS"):
         os.environ[v] = "1"
     try:
@@ -27,12 +27,12 @@ def _init(ansatz, fidelity):
         _G["tp"] = threadpool_limits(1)
     except Exception:  # pragma: no cover - threadpoolctl is optional
         pass
-    _G["ansatz"], _G["fid"] = ansatz, fidelity
+    _G["ansatz"], _G["fid"], _G["chi"] = ansatz, fidelity, max_bond
 
 
 def _one(x):
     t0 = time.perf_counter()
-    m = simulate(_G["ansatz"].circuit_for_data(x), _G["fid"])
+    m = simulate(_G["ansatz"].circuit_for_data(x), _G["fid"], max_bond=_G.get("chi"))
     return m.tensors, m.fidelity, time.perf_counter() - t0
 
 
@@ -55,16 +55,16 @@ def default_workers() -> int:
     return max(1, min(n, cap))
 
 
-def build_states(ansatz, X, truncation_fidelity, workers=None):
+def build_states(ansatz, X, truncation_fidelity, workers=None, max_bond=None):
     """Return (list[MPS], per-state build seconds) for the rows of ``X``."""
     X = np.asarray(X, dtype=np.float64)
     workers = default_workers() if workers is None else int(workers)
     workers = min(workers, len(X)) or 1
     if workers <= 1:
-        _init(ansatz, truncation_fidelity)
+        _init(ansatz, truncation_fidelity, max_bond)
         res = [_one(x) for x in X]
     else:
         ctx = mp.get_context("fork")
-        with ctx.Pool(workers, initializer=_init, initargs=(ansatz, truncation_fidelity)) as pool:
+        with ctx.Pool(workers, initializer=_init, initargs=(ansatz, truncation_fidelity, max_bond)) as pool:
             res = pool.map(_one, list(X), chunksize=1)
     return [MPS(t, f) for t, f, _ in res], [dt for _, _, dt in res]

@@ -26,10 +26,11 @@ def main() -> None:
             break
         if task is None:
             break
-        idx, circuit, fidelity, zero = task
+        idx, circuit, fidelity, zero = task[:4]
+        max_bond = task[4] if len(task) > 4 else None
         t0 = time.perf_counter()
         try:
-            m = simulate(circuit, fidelity, zero)
+            m = simulate(circuit, fidelity, zero, max_bond)
             reply = (idx, m.tensors, m.fidelity, time.perf_counter() - t0, None)
         except Exception as exc:  # reported to the parent, which raises
             reply = (idx, None, 0.0, 0.0, repr(exc))

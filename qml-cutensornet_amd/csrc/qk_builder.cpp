@@ -131,8 +131,16 @@ int qkb_init(const char* openblas_path) {
 // MPS of circuit |0...0>.  op/q0/alpha: the bound gate program (ansatz.py: BoundCircuit).  On success fills
 // dims_out[n_qubits + 1] and *tensors_out: ONE malloc'd block holding the site tensors back to back, complex128
 // [l][2][r] row-major (free it with qkb_free), and *fidelity.  Returns 0, or a negative code with qkb_last_error().
+int qkb_simulate_chi(int32_t n_qubits, int32_t n_ops, const int8_t* op, const int32_t* q0, const double* alpha, double trunc_budget,
+                     double value_of_zero, int32_t max_bond, int32_t* dims_out, double** tensors_out, int64_t* n_complex_out, double* fidelity_out);
 int qkb_simulate(int32_t n_qubits, int32_t n_ops, const int8_t* op, const int32_t* q0, const double* alpha, double trunc_budget,
                  double value_of_zero, int32_t* dims_out, double** tensors_out, int64_t* n_complex_out, double* fidelity_out) {
+  return qkb_simulate_chi(n_qubits, n_ops, op, q0, alpha, trunc_budget, value_of_zero, 0, dims_out, tensors_out, n_complex_out, fidelity_out);
+}
+// max_bond > 0: at most that many singular values survive a gate (the chi of pytket-cutensornet's Config, reference
+// gpu_backend/kernel_state_ansatz.py:141-144); the lost weight goes into the fidelity like any other truncation.
+int qkb_simulate_chi(int32_t n_qubits, int32_t n_ops, const int8_t* op, const int32_t* q0, const double* alpha, double trunc_budget,
+                     double value_of_zero, int32_t max_bond, int32_t* dims_out, double** tensors_out, int64_t* n_complex_out, double* fidelity_out) {
   if (!p_zgesdd) {
     g_err = "qkb_init has not been called";
     return -1;
@@ -266,7 +274,14 @@ int qkb_simulate(int32_t n_qubits, int32_t n_ops, const int8_t* op, const int32_
       return -5;
     }
     double frac = 1.0;
-    const int keep = kept(S, trunc_budget, value_of_zero, &frac);
+    int keep = kept(S, trunc_budget, value_of_zero, &frac);
+    if (max_bond > 0 && keep > max_bond) {  // the chi cap
+      keep = max_bond;
+      double tot = 0, w = 0;
+      for (double x : S) tot += x * x;
+      for (int j = 0; j < keep; ++j) w += S[j] * S[j];
+      frac = w / tot;
+    }
     fidelity *= frac;
     double nrm = 0;
     for (int j = 0; j < keep; ++j) nrm += S[j] * S[j];

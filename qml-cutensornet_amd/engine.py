@@ -96,6 +96,7 @@ _SIGNATURES = [
     ("qk_built_destroy", C.c_int, [_P]),
     ("qk_mps_set_from_built", C.c_int, [_P, _P, C.POINTER(_P)]),
     ("qk_debug_jacobi", C.c_int, [_P, C.c_int32, C.c_int32, _P, _P, _P, _P]),
+    ("qk_debug_jacobi_precond", C.c_int, [_P, C.c_int32, C.c_int32, _P, _P, _P, _P, _P]),
     ("qk_range_push", C.c_int, [C.c_char_p]),
     ("qk_range_pop", C.c_int, []),
     ("qk_comm_init_all", C.c_int, [C.c_int32, _P, C.POINTER(_P)]),
@@ -173,6 +174,15 @@ def _check(rc: int, what: str):
 
 def device_count() -> int:
     return int(lib().qk_device_count())
+
+
+def range_push(name: str) -> None:
+    """Open a roctx range (visible to ``rocprofv3 --marker-trace``; a no-op unless a profiler is attached or QK_ROCTX=1)."""
+    lib().qk_range_push(name.encode())
+
+
+def range_pop() -> None:
+    lib().qk_range_pop()
 
 
 def _dims_table(states) -> np.ndarray:
@@ -379,7 +389,19 @@ class Context:
         _check(lib().qk_debug_jacobi(self._h, p, q, a.ctypes.data, v.ctypes.data, sig.ctypes.data, order.ctypes.data), "qk_debug_jacobi")
         return a, v, sig, order
 
-    def build_mps(self, circuits, truncation_fidelity: float = 1.0 - 1e-16, value_of_zero: float = 1e-16, max_bond: int = 256, partial: bool = False):
+    def debug_jacobi_precond(self, a):
+        """The builder's preconditioned block factorisation on one matrix (p x q, 16 <= q): (W = A V, V, sig, ord, sweeps, ms)."""
+        a = np.ascontiguousarray(a, dtype=np.complex128).copy()
+        p, q = a.shape
+        v = np.zeros((q, q), dtype=np.complex128)
+        sig = np.zeros(q, dtype=np.float64)
+        ord_ = np.zeros(q, dtype=np.int32)
+        st = np.zeros(6, dtype=np.int32)
+        _check(lib().qk_debug_jacobi_precond(self._h, p, q, a.ctypes.data, v.ctypes.data, sig.ctypes.data, ord_.ctypes.data, st.ctypes.data), "qk_debug_jacobi_precond")
+        self.last_precond_ms = [float(np.uint32(t)) / 1e5 for t in st[1:]]  # all, sort + copy, Gram-Schmidt, sweeps, V and W = A V
+        return a, v, sig, ord_, int(st[0]), self.last_precond_ms[0]
+
+    def build_mps(self, circuits, truncation_fidelity: float = 1.0 - 1e-16, value_of_zero: float = 1e-16, max_bond: int = 256, partial: bool = False, truncate: bool = False):
         """Device MPS builder (/root/reference/gpu_backend/kernel_state_ansatz.py:221, 263): the MPS of every
         bound circuit of the list (``ansatz.BoundCircuit``; they must share one gate structure, as the data points of one
         ansatz do) in ONE launch.  Returns (list[MPS], info) with info = {"kernel_ms", "total_complex", "dropped"}.  With
@@ -400,7 +422,7 @@ class Context:
         n, ns = int(c0.n_qubits), len(circuits)
         h = _P()
         _check(lib().qk_build_mps(self._h, ns, n, int(op.shape[0]), op.ctypes.data, q0.ctypes.data, alpha.ctypes.data,
-                                  max(0.0, 1.0 - float(truncation_fidelity)), float(value_of_zero), int(max_bond), 1 if partial else 0, C.byref(h)), "qk_build_mps")
+                                  max(0.0, 1.0 - float(truncation_fidelity)), float(value_of_zero), int(max_bond), (1 if partial else 0) | (2 if truncate else 0), C.byref(h)), "qk_build_mps")
         try:
             dims = np.zeros((ns, n + 1), dtype=np.int32)
             fid = np.zeros(ns, dtype=np.float64)
@@ -425,7 +447,7 @@ class Context:
             states.append(MPS(tensors, float(fid[s_])))
         return states, {"kernel_ms": ms.value, "total_complex": int(total.value), "dropped": dropped}
 
-    def build_mps_set(self, circuits, truncation_fidelity: float = 1.0 - 1e-16, value_of_zero: float = 1e-16, max_bond: int = 256):
+    def build_mps_set(self, circuits, truncation_fidelity: float = 1.0 - 1e-16, value_of_zero: float = 1e-16, max_bond: int = 256, truncate: bool = False):
         """Like ``build_mps`` but the states never leave the device: returns (MpsSet, info) with info = {"kernel_ms", "dims",
         "fidelity"}; the set feeds ``gram`` / ``gram_values`` directly."""
         circuits = list(circuits)
@@ -441,7 +463,7 @@ class Context:
         n, ns = int(c0.n_qubits), len(circuits)
         h, hs = _P(), _P()
         _check(lib().qk_build_mps(self._h, ns, n, int(op.shape[0]), op.ctypes.data, q0.ctypes.data, alpha.ctypes.data,
-                                  max(0.0, 1.0 - float(truncation_fidelity)), float(value_of_zero), int(max_bond), 0, C.byref(h)), "qk_build_mps")
+                                  max(0.0, 1.0 - float(truncation_fidelity)), float(value_of_zero), int(max_bond), 2 if truncate else 0, C.byref(h)), "qk_build_mps")
         try:
             dims = np.zeros((ns, n + 1), dtype=np.int32)
             fid = np.zeros(ns, dtype=np.float64)
@@ -462,7 +484,7 @@ class Context:
                "qk_mps_set_from_packed")
         return MpsSet(self, h, dims)
 
-    def build_share(self, circuits, truncation_fidelity: float = 1.0 - 1e-16, value_of_zero: float = 1e-16, max_bond: int = 256, partial: bool = False):
+    def build_share(self, circuits, truncation_fidelity: float = 1.0 - 1e-16, value_of_zero: float = 1e-16, max_bond: int = 256, partial: bool = False, truncate: bool = False):
         """Device builder for one rank's share of a data set, the states staying on the device whenever possible: returns
         (MpsSet, None, info) when every state fitted ``max_bond`` (packed on the device by ``qk_mps_set_from_built``: nothing
         is downloaded), else (None, list[MPS | None], info) with the dropped states ``None`` (``partial`` only), to be
@@ -482,7 +504,7 @@ class Context:
         n, ns = int(c0.n_qubits), len(circuits)
         h = _P()
         _check(lib().qk_build_mps(self._h, ns, n, int(op.shape[0]), op.ctypes.data, q0.ctypes.data, alpha.ctypes.data,
-                                  max(0.0, 1.0 - float(truncation_fidelity)), float(value_of_zero), int(max_bond), 1 if partial else 0, C.byref(h)), "qk_build_mps")
+                                  max(0.0, 1.0 - float(truncation_fidelity)), float(value_of_zero), int(max_bond), (1 if partial else 0) | (2 if truncate else 0), C.byref(h)), "qk_build_mps")
         try:
             dims = np.zeros((ns, n + 1), dtype=np.int32)
             fid = np.zeros(ns, dtype=np.float64)

@@ -128,45 +128,63 @@ def _hybrid_build(ctx, circuits, fidelity, cap, host_workers, is_root, label):
     return states, secs
 
 
+def _auto_builder(circuits, host_workers):
+    """QK_BUILDER=auto: device or host for this share, from its size, the host cores at hand and the spread of the cost proxy.
+    Calibration (one MI355X box with a 16-core share, profiles/r03/builder_policy.txt): the device builder runs a state per
+    workgroup -- 256 to 1024 in flight -- and a launch ends with its heaviest state, which takes about 2.5 x what one host
+    core needs for it (60 qubits x 6 layers, gamma = 1: 4.3 s for the longest of 500 states, whose sum is 230-430 cpu-s).
+    The host pool needs (states x mean cost) / workers.  With the heaviest state at (w_max / w_mean)^2 times the mean cost the
+    device wins from about 2.5 x workers x (w_max / w_mean)^2 states on: 500 states of that config (ratio 2.5) and 1000 of the
+    100-qubit gamma = 0.1 one (ratio 1.1) go to the device, a share of 63 of the former stays on 16 host cores."""
+    m = len(circuits)
+    if m == 0:
+        return "host"
+    w = np.array([_entangling_weight(c) for c in circuits])
+    ratio = float(w.max() / w.mean()) if w.mean() > 0 else 1.0
+    need = 2.5 * max(1, host_workers) * max(1.0, ratio) ** 2
+    return "device" if m >= need else "host"
+
+
 def _simulate_share(ansatz, points, rank, n_procs, fidelity, is_root, label, device_id=0, host_workers=1, want_set=True):
     """This rank's slice of the data set (contiguous chunks of ceil(N/P), as ref :154,:171-174) -> (first index, the
     states as ONE packed device set -- ``None`` for an empty share --, seconds per state, fidelities).  ``want_set=False``
-    (host-only callers: the CPU tests) keeps the host builder's list of MPS instead of uploading it."""
+    (host-only callers: the CPU tests) keeps the host builder's list of MPS instead of uploading it.
+    QK_MAX_BOND (environment): a bond cap for either builder -- the ``chi`` pytket-cutensornet's ``Config`` would take at
+    ref :141-144 (the reference leaves it unset: the default is no cap)."""
     import os
 
     per_rank = -(-len(points) // n_procs)
     lo = min(len(points), rank * per_rank)
     hi = min(len(points), lo + per_rank)
+    chi = int(os.environ.get("QK_MAX_BOND", "0")) or None
     which = os.environ.get("QK_BUILDER", "auto") if want_set else "host"  # auto | device | hybrid | host
+    forced = which  # what the caller asked for: only a FORCED device build may fail the call
+    circuits = [ansatz.circuit_for_data(points[k, :]) for k in range(lo, hi)] if hi > lo else []
     if which == "auto":
-        # "never lose": the device builder takes the share only where it is known to win -- every bond is bounded by
-        # 2^(distance x layers) <= 64 (no state can outgrow the cap: one launch, nothing downloaded) and the share is large
-        # enough to fill the GPU (a state occupies one workgroup).  Elsewhere the host pool is at least as fast
-        # (profiles/r02/builder_policy.txt); QK_BUILDER=hybrid runs both at once behind a pilot, QK_BUILDER=device forces it.
-        dist_max = max((abs(int(b_) - int(a_)) for a_, b_ in getattr(ansatz, "entanglement_map", [])), default=0)
-        bound = 2 ** min(dist_max * int(getattr(ansatz, "reps", 0)), int(ansatz.num_qubits) // 2)
-        which = "device" if (bound <= 64 and hi - lo >= 32) else "host"
+        try:
+            which = _auto_builder(circuits, host_workers)
+        except (AttributeError, TypeError, ValueError):  # an ansatz without a compiled gate program: the host loop handles it
+            which = "host"
     if which in ("device", "hybrid") and hi > lo:
         # the rank's whole share in ONE launch of the device builder (csrc/qk_build.hip): what the reference does with
-        # simulate(libhandle, ...) on the rank's GPU (ref :221,:263).  Pays off at the small bonds of the reference's own
-        # runs (profiles/r01/device_builder_bench.txt).  "device" uses it alone (max_bond 256) and fails on overflow;
-        # "hybrid" caps its bonds at 64 and builds what outgrows the cap on the host pool -- concurrently, behind a pilot,
-        # for shares of >= 24 states (_hybrid_build); "host" skips it.
+        # simulate(libhandle, ...) on the rank's GPU (ref :221,:263).  "device" / "auto": bonds up to QK_BUILDER_MAX_BOND (320:
+        # bonds in mid-circuit exceed the final ones), a state that outgrows it is built on the host afterwards (a forced
+        # "device" fails instead); "hybrid" caps at 64 and builds what outgrows the cap on the host pool -- concurrently, behind a
+        # pilot, for shares of >= 24 states (_hybrid_build); "host" skips it.
         t0 = time.perf_counter()
-        cap = int(os.environ.get("QK_BUILDER_MAX_BOND", "256" if which == "device" else "64"))
-        partial = which == "hybrid"
-        circuits = [ansatz.circuit_for_data(points[k, :]) for k in range(lo, hi)]
+        cap = chi or int(os.environ.get("QK_BUILDER_MAX_BOND", "64" if which == "hybrid" else "320"))
+        partial = which == "hybrid" or (forced == "auto" and chi is None)
         ctx = _engine.default_context(device_id)
-        if which == "hybrid" and hi - lo >= _PILOT_MIN_STATES:
+        if which == "hybrid" and hi - lo >= _PILOT_MIN_STATES and chi is None:
             out = _hybrid_build(ctx, circuits, fidelity, cap, host_workers, is_root, label)
             if out is not None:
                 states, secs = out
                 _say(is_root, f"{label}: 100%")
                 return lo, ctx.upload(states), secs, [m.fidelity for m in states]
         try:
-            dset, states, binfo = ctx.build_share(circuits, fidelity, max_bond=cap, partial=partial)
+            dset, states, binfo = ctx.build_share(circuits, fidelity, max_bond=cap, partial=partial, truncate=chi is not None)
         except _engine.QkError as exc:
-            if which == "device":
+            if forced == "device":
                 raise
             _say(is_root, f"{label}: device builder gave up ({exc}); building on the host")
             dset, states, binfo = None, None, None
@@ -192,7 +210,7 @@ def _simulate_share(ansatz, points, rank, n_procs, fidelity, is_root, label, dev
         if (done[0] - 1) % tick == 0:
             _say(is_root, f"{label}: {10 * ((done[0] - 1) // tick)}%")
 
-    states, secs = simulate_many([ansatz.circuit_for_data(points[k, :]) for k in range(lo, hi)], fidelity, workers=host_workers, progress=progress)
+    states, secs = simulate_many(circuits, fidelity, workers=host_workers, progress=progress, max_bond=chi)
     if not want_set:
         return lo, states, secs, [m.fidelity for m in states]
     if not states:

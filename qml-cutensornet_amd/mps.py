@@ -139,8 +139,8 @@ def _native_builder():
             lib = C.CDLL(os.path.join(here, "libqkbuilder.so"))
             lib.qkb_last_error.restype = C.c_char_p
             lib.qkb_init.argtypes = [C.c_char_p]
-            lib.qkb_simulate.argtypes = [C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_double,
-                                         C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int64), C.POINTER(C.c_double)]
+            lib.qkb_simulate_chi.argtypes = [C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_double, C.c_int32,
+                                             C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int64), C.POINTER(C.c_double)]
             lib.qkb_free.argtypes = [C.c_void_p]
             if blas and lib.qkb_init(os.path.realpath(blas[0]).encode()) == 0:
                 _NATIVE = lib
@@ -149,7 +149,7 @@ def _native_builder():
     return _NATIVE or None
 
 
-def simulate_native(circuit: BoundCircuit, truncation_fidelity: float = 1.0 - 1e-16, value_of_zero: float = 1e-16) -> MPS:
+def simulate_native(circuit: BoundCircuit, truncation_fidelity: float = 1.0 - 1e-16, value_of_zero: float = 1e-16, max_bond: int | None = None) -> MPS:
     """``simulate`` through the native builder: same algorithm and LAPACK routines, no interpreter in the gate loop."""
     import ctypes as C
 
@@ -162,8 +162,8 @@ def simulate_native(circuit: BoundCircuit, truncation_fidelity: float = 1.0 - 1e
     alpha = np.ascontiguousarray(circuit.alpha, dtype=np.float64)
     dims = np.zeros(n + 1, dtype=np.int32)
     block, count, fid = C.c_void_p(), C.c_int64(), C.c_double()
-    rc = lib.qkb_simulate(n, int(op.shape[0]), op.ctypes.data, q0.ctypes.data, alpha.ctypes.data, max(0.0, 1.0 - float(truncation_fidelity)),
-                          float(value_of_zero), dims.ctypes.data, C.byref(block), C.byref(count), C.byref(fid))
+    rc = lib.qkb_simulate_chi(n, int(op.shape[0]), op.ctypes.data, q0.ctypes.data, alpha.ctypes.data, max(0.0, 1.0 - float(truncation_fidelity)),
+                              float(value_of_zero), int(max_bond or 0), dims.ctypes.data, C.byref(block), C.byref(count), C.byref(fid))
     if rc != 0:
         raise RuntimeError(f"native MPS builder failed: {lib.qkb_last_error().decode()}")
     try:
@@ -178,8 +178,10 @@ def simulate_native(circuit: BoundCircuit, truncation_fidelity: float = 1.0 - 1e
     return MPS(tensors, fid.value)
 
 
-def simulate(circuit: BoundCircuit, truncation_fidelity: float = 1.0 - 1e-16, value_of_zero: float = 1e-16) -> MPS:
-    """MPS of circuit|0...0>, "MPSxGate" style: one SVD per two-qubit gate (ref :221).
+def simulate(circuit: BoundCircuit, truncation_fidelity: float = 1.0 - 1e-16, value_of_zero: float = 1e-16, max_bond: int | None = None) -> MPS:
+    """MPS of circuit|0...0>, "MPSxGate" style: one SVD per two-qubit gate (ref :221).  ``max_bond``: at most that many singular
+    values survive a gate -- the ``chi`` of pytket-cutensornet's ``Config`` (ref :141-144 is where it would go); the weight it
+    costs goes into ``fidelity`` like any other truncation.
 
     The matrices are small (tens to a few hundred rows): a multi-threaded BLAS spends its time waking
     threads (measured 24 s instead of 0.9 s per 60-qubit state on 8 cores), so the LAPACK calls run
@@ -187,14 +189,14 @@ def simulate(circuit: BoundCircuit, truncation_fidelity: float = 1.0 - 1e-16, va
     try:
         from threadpoolctl import threadpool_limits
     except ImportError:  # pragma: no cover - optional dependency
-        return _simulate(circuit, truncation_fidelity, value_of_zero)
+        return _simulate(circuit, truncation_fidelity, value_of_zero, max_bond)
     with threadpool_limits(limits=1):
         if _use_native():
-            return simulate_native(circuit, truncation_fidelity, value_of_zero)
-        return _simulate(circuit, truncation_fidelity, value_of_zero)
+            return simulate_native(circuit, truncation_fidelity, value_of_zero, max_bond)
+        return _simulate(circuit, truncation_fidelity, value_of_zero, max_bond)
 
 
-def simulate_many(circuits, truncation_fidelity: float = 1.0 - 1e-16, value_of_zero: float = 1e-16, workers: int | None = None, progress=None):
+def simulate_many(circuits, truncation_fidelity: float = 1.0 - 1e-16, value_of_zero: float = 1e-16, workers: int | None = None, progress=None, max_bond: int | None = None):
     """``simulate`` for a list of circuits on several host cores **without forking** (safe once the GPU is initialised).
     The first circuit is built in this process and sizes the job: long jobs go to one worker *process* per core
     (``builder_worker.py`` over pipes: 10.8x on 16 cores for cfg4-shaped circuits, where threads in one process reach 2x
@@ -214,7 +216,7 @@ def simulate_many(circuits, truncation_fidelity: float = 1.0 - 1e-16, value_of_z
 
     def one(c):
         t0 = time.perf_counter()
-        m = simulate(c, truncation_fidelity, value_of_zero)
+        m = simulate(c, truncation_fidelity, value_of_zero, max_bond)
         if progress is not None:
             progress()
         return m, time.perf_counter() - t0
@@ -230,13 +232,13 @@ def simulate_many(circuits, truncation_fidelity: float = 1.0 - 1e-16, value_of_z
     if mode == "threads" and not _use_native():
         mode = "serial"
     if mode == "procs":
-        out, secs = _simulate_many_procs(rest, truncation_fidelity, value_of_zero, workers, progress)
+        out, secs = _simulate_many_procs(rest, truncation_fidelity, value_of_zero, workers, progress, max_bond)
     elif mode == "threads":
         from concurrent.futures import ThreadPoolExecutor
 
         def one_native(c):  # simulate() would enter / leave the BLAS thread limit per call, racing across threads
             t0 = time.perf_counter()
-            m = simulate_native(c, truncation_fidelity, value_of_zero)
+            m = simulate_native(c, truncation_fidelity, value_of_zero, max_bond)
             if progress is not None:
                 progress()
             return m, time.perf_counter() - t0
@@ -259,7 +261,7 @@ def simulate_many(circuits, truncation_fidelity: float = 1.0 - 1e-16, value_of_z
     return [first] + out, [t_first] + secs
 
 
-def _simulate_many_procs(circuits, truncation_fidelity, value_of_zero, workers, progress):
+def _simulate_many_procs(circuits, truncation_fidelity, value_of_zero, workers, progress, max_bond=None):
     """One interpreter per core (builder_worker.py) fed over pipes by one thread each; tasks are handed out one at a time,
     so uneven circuits balance themselves."""
     import pickle
@@ -282,7 +284,7 @@ def _simulate_many_procs(circuits, truncation_fidelity, value_of_zero, workers, 
                     nxt[0] += 1
                 if i >= len(circuits) or errors:
                     break
-                pickle.dump((i, circuits[i], truncation_fidelity, value_of_zero), pr.stdin, protocol=4)
+                pickle.dump((i, circuits[i], truncation_fidelity, value_of_zero, max_bond), pr.stdin, protocol=4)
                 pr.stdin.flush()
                 idx, tensors, fid, dt, err = pickle.load(pr.stdout)
                 if err is not None:
@@ -320,7 +322,7 @@ def _use_native() -> bool:
     return os.environ.get("QK_NATIVE_BUILDER", "1") != "0" and _native_builder() is not None
 
 
-def _simulate(circuit: BoundCircuit, truncation_fidelity: float, value_of_zero: float) -> MPS:
+def _simulate(circuit: BoundCircuit, truncation_fidelity: float, value_of_zero: float, max_bond: int | None = None) -> MPS:
     n = circuit.n_qubits
     budget = max(0.0, 1.0 - float(truncation_fidelity))
     A = []
@@ -380,6 +382,9 @@ def _simulate(circuit: BoundCircuit, truncation_fidelity: float, value_of_zero: 
             overwrite_a=True,
         )
         keep, frac = _kept(s, budget, value_of_zero)
+        if max_bond and keep > max_bond:  # the chi cap
+            keep = int(max_bond)
+            frac = float((s[:keep] ** 2).sum() / (s ** 2).sum())
         fidelity *= frac
         s = s[:keep]
         s = s / np.sqrt(float((s * s).sum()))

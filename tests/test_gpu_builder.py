@@ -224,24 +224,121 @@ def test_hybrid_builder_policy(gpu_ctx, monkeypatch, capsys):
     assert max(m.max_bond() for m in states) > 8  # (so the cap did bite: those states came from the host pool)
 
 
-def test_auto_builder_uses_the_device_only_where_it_cannot_lose(built, monkeypatch, capsys):
-    """QK_BUILDER=auto (the default): device builder iff every bond is bounded by 2^(distance x layers) <= 64 and the share has
-    >= 32 states (one launch, the share stays on the device); host pool otherwise.  Same Gram either way."""
+def test_auto_builder_policy_and_fallback(built, monkeypatch, capsys):
+    """QK_BUILDER=auto (the default): the device builder takes a share when it holds at least 2.5 x host workers x (w_max / w_mean)^2
+    states (w = the entangling weight of a circuit: the launch ends with its heaviest state), the host pool otherwise -- same Gram
+    either way; a device failure in auto mode falls back to the host, a FORCED device build raises; QK_MAX_BOND caps the bonds of
+    either builder the same way."""
     import qml_cutensornet_amd as Q
     from oracle import restatement as R
+    from qml_cutensornet_amd import engine
     from qml_cutensornet_amd.dist import SingleComm
     from qml_cutensornet_amd.gpu_backend import kernel_state_ansatz as M
 
-    monkeypatch.setenv("QK_BUILDER", "auto")
-    n = 16  # (bonds are also bounded by 2^(n/2) = 256 here, above the cap)
+    n = 16
     X = R.synthetic_features(40, n, 3)
+    ans = Q.KernelStateAnsatz(n, 3, 1.0, Q.entanglement_graph(n, 2))
+    circuits = [ans.circuit_for_data(x) for x in X]
+    w = np.array([M._entangling_weight(c) for c in circuits])
+    ratio2 = (w.max() / w.mean()) ** 2
+    assert M._auto_builder(circuits, 1) == "device" and 40 >= 2.5 * ratio2  # one host core: the device takes 40 states
+    assert M._auto_builder(circuits, 64) == "host"  # 64 cores would need >= 160 states
+    assert M._auto_builder(circuits[:3], 2) == "host"
     calls = []
     real = M._engine.Context.build_share
     monkeypatch.setattr(M._engine.Context, "build_share", lambda self, *a, **k: (calls.append(len(a[0])), real(self, *a, **k))[1])
-    for reps, d, expect_device in ((2, 2, True), (4, 2, False)):
+    K_ref = R.gram_from_mps([Q.simulate(c, 1 - 1e-16).tensors for c in circuits[:6]])
+    for workers, expect_device in (("1", True), ("64", False)):
         calls.clear()
-        ans = Q.KernelStateAnsatz(n, reps, 1.0, Q.entanglement_graph(n, d))
+        monkeypatch.setenv("QK_BUILDER", "auto")
+        monkeypatch.setattr(M, "default_workers", lambda: int(workers), raising=False)
+        monkeypatch.setenv("QK_BUILD_WORKERS", workers)
         K = M.build_kernel_matrix(SingleComm(), ans, X=X, truncation_error=1e-16)
-        assert (calls == [40]) == expect_device
-        K_ref = R.gram_from_mps([Q.simulate(ans.circuit_for_data(x), 1 - 1e-16).tensors for x in X[:6]])
         assert np.abs(K[:6, :6] - K_ref).max() < 1e-9
+        if expect_device:
+            assert calls == [40]
+    # auto falls back to the host when the device builder gives up; a forced device build does not
+    def boom(self, *a, **k):
+        raise engine.QkError("qk_build_mps: injected failure")
+
+    monkeypatch.setattr(M._engine.Context, "build_share", boom)
+    monkeypatch.setenv("QK_BUILD_WORKERS", "1")
+    monkeypatch.setenv("QK_BUILDER", "auto")
+    K = M.build_kernel_matrix(SingleComm(), ans, X=X[:12], truncation_error=1e-16)
+    assert np.abs(K[:6, :6] - K_ref).max() < 1e-9
+    monkeypatch.setenv("QK_BUILDER", "device")
+    with pytest.raises(engine.QkError, match="injected"):
+        M.build_kernel_matrix(SingleComm(), ans, X=X[:12], truncation_error=1e-16)
+    monkeypatch.setattr(M._engine.Context, "build_share", real)
+    # the bond cap: device and host builders truncate to the same bonds and (to rounding) the same states
+    monkeypatch.setenv("QK_MAX_BOND", "6")
+    Ks = {}
+    for which in ("device", "host"):
+        monkeypatch.setenv("QK_BUILDER", which)
+        Ks[which] = M.build_kernel_matrix(SingleComm(), ans, X=X[:10], truncation_error=1e-16)
+    assert np.abs(Ks["device"] - Ks["host"]).max() < 1e-8
+    capped = Q.simulate(circuits[0], 1 - 1e-16, max_bond=6)
+    assert capped.max_bond() == 6 and capped.fidelity < 1 - 1e-6 and Q.simulate(circuits[0], 1 - 1e-16).max_bond() > 6
+
+
+def _graded(rng, p, q, decades):
+    u, _ = np.linalg.qr(rng.standard_normal((p, q)) + 1j * rng.standard_normal((p, q)))
+    v, _ = np.linalg.qr(rng.standard_normal((q, q)) + 1j * rng.standard_normal((q, q)))
+    return (u * 10.0 ** (-decades * np.arange(q) / max(1, q - 1))) @ v.conj().T
+
+
+@pytest.mark.parametrize("kind,p,q,par", [("random", 64, 48, None), ("random", 130, 100, None), ("rank", 96, 64, 20), ("graded", 78, 66, 22), ("graded", 160, 128, 22),
+                                          ("graded", 300, 256, 22), ("graded", 512, 272, 14)])
+@pytest.mark.parametrize("wide", [False, True])
+def test_preconditioned_block_factorisation_against_lapack(gpu_ctx, monkeypatch, kind, p, q, par, wide):
+    """The builder's factorisation for matrices beyond its LDS working set (sorted columns, Gram-Schmidt R, block Jacobi of R^H on
+    the f64 matrix cores, W = A V) against LAPACK, in both workgroup shapes: singular values of the part the truncation keeps to
+    1e-13 of the largest (LAPACK's own accuracy is eps x that), W = A V, the kept part of the decomposition to 1e-12 of the norm,
+    V orthonormal to 1e-11.  Graded matrices are what a gate's theta looks like."""
+    if wide:
+        monkeypatch.setenv("QK_BUILD_WGS", "1")
+    rng = np.random.default_rng(p + q)
+    if kind == "random":
+        a = rng.standard_normal((p, q)) + 1j * rng.standard_normal((p, q))
+    elif kind == "rank":
+        a = (rng.standard_normal((p, par)) + 1j * rng.standard_normal((p, par))) @ (rng.standard_normal((par, q)) + 1j * rng.standard_normal((par, q)))
+    else:
+        a = _graded(rng, p, q, par)
+    w, v, sig, order, sweeps, _ = gpu_ctx.debug_jacobi_precond(a)
+    u_ref, s_ref, vh_ref = np.linalg.svd(a, full_matrices=False)
+    tot = (s_ref ** 2).sum()
+    keep = int((np.cumsum((s_ref ** 2)[::-1])[::-1] > 1e-16 * tot).sum())
+    assert int((sig > 0).sum()) >= keep and sweeps <= 16
+    sg = sig[order]
+    wk, vk = w[:, order[:keep]], v[:, order[:keep]]
+    assert np.abs(sg[:keep] - s_ref[:keep]).max() < 1e-13 * s_ref[0]  # (LAPACK's own values are good to eps x the largest one)
+    assert np.abs(a @ vk - wk).max() < 1e-13 * s_ref[0]
+    assert np.abs(wk @ vk.conj().T - (u_ref[:, :keep] * s_ref[:keep]) @ vh_ref[:keep]).max() < 1e-12 * s_ref[0]
+    assert np.abs(vk.conj().T @ vk - np.eye(keep)).max() < 1e-11
+
+
+def test_device_builder_at_bonds_up_to_256(gpu_ctx):
+    """The heaviest states of the 60-qubit x 6-layer headline set (bonds to 248, thetas of 500 x 500 through the preconditioned block
+    factorisation) and a 28-qubit x 7-layer set: device-built against host-built -- |<dev|host>|^2 = 1 to 1e-10, the same bonds,
+    the same fidelity."""
+    import qml_cutensornet_amd as Q
+    from oracle import restatement as R
+    from qml_cutensornet_amd.data import synthetic_features
+
+    for n, reps, X, pick in ((28, 7, R.synthetic_features(6, 28, 11), 4), (60, 6, synthetic_features(500, 60, 5), 3)):
+        ans = Q.KernelStateAnsatz(n, reps, 1.0, Q.entanglement_graph(n, 2))
+        circs = [ans.circuit_for_data(x) for x in X]
+        if n == 60:
+            w = np.array([float((np.sin(np.pi * np.asarray(c.alpha)[np.asarray(c.op) == 2]) ** 2).sum()) for c in circs])
+            circs = [circs[i] for i in np.argsort(-w)[:pick]]
+        else:
+            circs = circs[:pick]
+        dev, info = gpu_ctx.build_mps(circs, max_bond=320)
+        host = [Q.simulate(c, 1 - 1e-16) for c in circs]
+        assert max(m.max_bond() for m in host) > (150 if n == 28 else 200)
+        with gpu_ctx.upload(dev) as xs, gpu_ctx.upload(host) as ys:
+            z = np.abs(np.diag(gpu_ctx.overlaps(xs, ys))) ** 2
+        assert np.abs(z - 1).max() < 1e-10
+        for a, b in zip(dev, host):
+            assert np.array_equal(a.bond_dims(), b.bond_dims())
+            assert abs(a.fidelity - b.fidelity) < 1e-12

@@ -87,13 +87,14 @@ def test_four_rank_bench_rehearsal(built, tmp_path):
     assert d["config"]["diag_err"] < 1e-11 and d["config"]["sym_err"] == 0.0
     ms, work = np.array(d["config"]["rank_kernel_ms"]), np.array(d["config"]["rank_padded_tflop"])
     assert len(ms) == 4 and ms.min() > 0  # (four processes time-share ONE GPU here: their kernel times say nothing about balance)
-    assert work.max() / work.min() < 1.01, work  # the serpentine deal of the cost-ordered pairs: equal shares of the padded work
+    assert work.max() / work.min() < 1.02, work  # tiles dealt by cost, the lightest pair by pair: level shares of the padded work
+    assert len(d["config"]["rank_tail_frac"]) == 4
 
 
 @pytest.mark.timeout(600)
 def test_bench_line_contract(built, tmp_path):
     """`python bench.py` on one GPU (a reduced workload: 60 points of cfg4, whose states differ enough for the split sweep):
-    ONE JSON line with the driver's keys, the roofline object of the dominant launch (and of the second launch beside it),
+    ONE JSON line with the driver's keys, the roofline object of the whole sweep (its launches listed beside it),
     the CPU baseline timed on a bounded sample and checked against the GPU values."""
     env = dict(os.environ, QK_CACHE_DIR=str(tmp_path / "cache"))
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--points", "60", "--steps", "2", "--warmup", "1", "--cpu-seconds", "2"]
@@ -108,18 +109,25 @@ def test_bench_line_contract(built, tmp_path):
     assert "workload" in d["config"] and "model" not in d["config"]
     assert abs(d["value"] - 60 * 60 / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
     rf = d["roofline"]
-    for key in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "kernel_ms"):
+    for key in ("bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_source", "kernel", "kernel_ms", "launches", "work_queues"):
         assert key in rf, key
+    # the roofline object prices the WHOLE sweep (both launches of a split one); the roof is chosen from the algorithmic intensity
     assert rf["bound"] == "mfma" and rf["unit"] == "TFLOP/s" and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12 and 0 < rf["frac"] < 1
-    assert rf["kernel"].startswith("qk_sweep_")
-    whole = rf["whole_sweep"]
-    if rf["second_launch"]:  # two launches: their device times add up to the whole sweep, their flops to the plan's
-        s2 = rf["second_launch"]
-        assert abs(rf["kernel_ms"] + s2["kernel_ms"] - whole["kernel_ms"]) < 1e-6 * whole["kernel_ms"]
-        assert abs(rf["algorithmic_tflop_per_launch"] + s2["algorithmic_tflop_per_launch"] - whole["algorithmic_tflop"]) < 1e-9 * whole["algorithmic_tflop"]
-        assert s2["kernel"].startswith("qk_sweep_fused_kernel<8")
-    else:
-        assert abs(rf["kernel_ms"] - whole["kernel_ms"]) < 1e-9
+    assert rf["algorithmic_flop_per_byte"] > rf["ridge_flop_per_byte"]
+    assert rf["kernel"].startswith("qk_sweep_") and rf["work_queues"] == 8
+    assert rf["traffic"] is None and rf["traffic_source"].startswith("none")  # a reduced workload: no committed PMC summary to quote
+    ls = rf["launches"]
+    assert 1 <= len(ls) <= 2
+    assert abs(sum(x["kernel_ms"] for x in ls) - rf["kernel_ms"]) < 1e-6 * rf["kernel_ms"]
+    assert abs(sum(x["algorithmic_tflop"] for x in ls) - rf["algorithmic_tflop_per_sweep"]) < 1e-9 * rf["algorithmic_tflop_per_sweep"]
+    assert abs(rf["achieved"] - rf["algorithmic_tflop_per_sweep"] / (rf["kernel_ms"] * 1e-3)) < 1e-9 * rf["achieved"]
+    for x in ls:
+        assert x["kernel"].startswith("qk_sweep_fused") and 0 <= x["tail_frac"] < 0.5
+    if len(ls) == 2:
+        assert ls[1]["kernel"].startswith("qk_sweep_fused_kernel<8")
+    mb = d["config"]["mps_build"]  # the input producer, host pool and device builder side by side (untimed)
+    assert mb["host_pool_s"] > 0 and mb["device_kernel_s"] > 0 and mb["largest_bond_difference"] <= 1
+    assert d["config"]["device_built_vs_host_built_gram_max_abs"] < 1e-9
     cb = d["cpu_baseline"]
     for key in ("value", "unit", "cores", "kind", "sample"):
         assert key in cb, key

@@ -52,3 +52,56 @@ def test_builder_with_the_model_reproduces_the_lapack_builder(n, reps, d, gamma,
         assert abs(abs(R.mps_inner(mod.tensors, ref.tensors)) ** 2 - 1) < 1e-10
         assert max(mod.bond_dims()) <= max(ref.bond_dims())
         assert abs(mod.fidelity - ref.fidelity) < 1e-10
+
+
+@pytest.mark.parametrize("p,q,decades", [(40, 32, 20), (78, 66, 22), (96, 96, 12)])
+def test_preconditioned_block_model_on_graded_matrices(p, q, decades):
+    """The device builder's factorisation for large matrices, restated (jacobi_precond: sorted columns, Gram-Schmidt R, block Jacobi
+    of R^H without accumulating rotations, W = A V), on GRADED matrices -- what a gate's theta looks like: about half the sweeps of
+    the plain method, the kept part of the decomposition as LAPACK gives it, V orthonormal."""
+    rng = np.random.default_rng(p * q)
+    u, _ = np.linalg.qr(rng.standard_normal((p, q)) + 1j * rng.standard_normal((p, q)))
+    v0, _ = np.linalg.qr(rng.standard_normal((q, q)) + 1j * rng.standard_normal((q, q)))
+    a = (u * 10.0 ** (-decades * np.arange(q) / (q - 1))) @ v0.conj().T
+    w, v, sig, sweeps = J.jacobi_precond(a)
+    _, _, _, plain = J.jacobi(a)
+    assert sweeps <= 12 and sweeps <= plain
+    u_ref, s_ref, vh_ref = np.linalg.svd(a, full_matrices=False)
+    keep = int((np.cumsum((s_ref ** 2)[::-1])[::-1] > 1e-16 * (s_ref ** 2).sum()).sum())
+    o = np.argsort(-sig, kind="stable")
+    assert np.abs(sig[o][:keep] - s_ref[:keep]).max() < 1e-14 * s_ref[0]  # (LAPACK's own values are good to eps x the largest one)
+    wk, vk = w[:, o[:keep]], v[:, o[:keep]]
+    assert np.abs(wk @ vk.conj().T - (u_ref[:, :keep] * s_ref[:keep]) @ vh_ref[:keep]).max() < 1e-12
+    assert np.abs(vk.conj().T @ vk - np.eye(keep)).max() < 1e-11
+
+
+def test_block_model_matches_the_scalar_model():
+    """Block Jacobi (8-column blocks, all pairs of a panel in a sweep's first round, cross pairs afterwards) is a cyclic ordering of
+    the scalar method: same singular values, A V = W, V unitary."""
+    rng = np.random.default_rng(3)
+    a = rng.standard_normal((50, 37)) + 1j * rng.standard_normal((50, 37))
+    w, v, sig, sweeps = J.jacobi_block(a)
+    s_ref = np.linalg.svd(a, compute_uv=False)
+    assert sweeps <= 12
+    assert np.abs(np.sort(sig)[::-1] - s_ref).max() < 1e-13 * s_ref[0]
+    assert np.abs(a @ v - w).max() < 1e-13 * np.abs(a).max()
+    assert np.abs(v.conj().T @ v - np.eye(37)).max() < 1e-13
+
+
+def test_builder_with_the_preconditioned_model_reproduces_the_lapack_builder(monkeypatch):
+    import qml_cutensornet_amd as Q
+    from oracle import restatement as R
+    from qml_cutensornet_amd import mps as M
+
+    n, reps, d = 10, 3, 3
+    X = R.synthetic_features(2, n, 5)
+    ans = Q.KernelStateAnsatz(n, reps, 1.0, Q.entanglement_graph(n, d))
+    for x in X:
+        c = ans.circuit_for_data(x)
+        ref = M._simulate(c, 1 - 1e-16, 1e-16)
+        with monkeypatch.context() as mp:
+            mp.setattr(M, "_svd", lambda a, **k: J.svd_precond_model(a) if min(a.shape) >= 16 else J.svd_model(a))
+            mp.setattr(M, "_qr", lambda a, **k: J.qr_precond_model(a) if min(a.shape) >= 16 else J.qr_model(a))
+            mod = M._simulate(c, 1 - 1e-16, 1e-16)
+        assert abs(abs(R.mps_inner(mod.tensors, ref.tensors)) ** 2 - 1) < 1e-10
+        assert np.array_equal(mod.bond_dims(), ref.bond_dims())
