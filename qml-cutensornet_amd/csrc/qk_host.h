@@ -1,7 +1,7 @@
 // qk_host.h -- host-side state shared by the translation units:
 //   qkgram.hip    the C ABI, the planner and the shipped sweep kernels      } libqkgram.so
 //   qk_build.hip  the device MPS builder                                    }
-//   qk_lab.hip    experimental / diagnostic kernels for A/B measurements: only in libqklab.so (-DQK_LAB, tools/)
+//   qk_lab.hip    experimental / diagnostic kernels for A/B measurements: only in lab/libqklab.so (-DQK_LAB, lab/tools)
 #pragma once
 #include "../../include/qkgram.h"
 
@@ -46,6 +46,7 @@ struct qk_ctx {
   bool small_path = true;  // sets whose bonds are all <= 32 use the LDS-resident small-bond sweep (QK_SMALL=0 opts out)
   bool fused_split = true;  // sweep the plan's two runs of pairs with the two shapes of the site-fused kernel (QK_FUSED_SPLIT=0: one shape)
   int fused_wgs = 0;       // workgroups per CU of the site-fused sweep: 0 = chosen per launch from the plan, 1 / 2 forced (QK_FUSED_WGS)
+  bool deterministic = false;  // QK_DETERMINISTIC=1: only kernels that add in a fixed order (no LDS atomics)
   int fused_path = 1;      // fp64 sets with a bond > 32 use the site-fused sweep (QK_FUSED=0: ring sweep instead; 2: also for bonds 17..32)
   qk_stats last{};
 };

@@ -12,7 +12,7 @@
 //
 // Files: this one = C ABI (include/qkgram.h), packing, planner, small kernels, launches;  qk_fused.h = the site-fused
 // sweep (the fp64 hot path) and the 2 x 2-tile one-wave sweep (fp64, bonds <= 32);  qk_ring.h = the ring sweep (complex64,
-// very large bonds), the LDS-resident small-bond sweep and the one-tile one-wave sweep;  qk_build.hip = the device MPS builder.  qk_lab.hip (experimental / diagnostic kernels) is NOT part of
+// very large bonds), the LDS-resident small-bond sweep and the one-tile one-wave sweep;  qk_build.hip = the device MPS builder.  lab/qk_lab.hip (experimental / diagnostic kernels) is NOT part of
 // libqkgram.so: it is linked only into libqklab.so (-DQK_LAB), which tools/ load for A/B measurements.
 // Written for gfx950 only: 64-lane wavefronts, 160 KiB LDS per CU, no portability layer.
 #include "qk_host.h"
@@ -675,6 +675,12 @@ static int ctx_init(qk_ctx* c, int device_id, int num_cus) {
   if (const char* v = std::getenv("QK_WAVE")) c->wave_path = std::atoi(v) != 0;
   if (const char* v = std::getenv("QK_WAVE2")) c->wave2_path = std::atoi(v) != 0, c->wave2_ring = std::atoi(v) != 2;
   if (const char* v = std::getenv("QK_FUSED")) c->fused_path = std::atoi(v);
+  // QK_DETERMINISTIC=1: bit-reproducible Grams.  The site-fused sweep sums the tiles of a column with LDS atomics in arrival
+  // order (two launches on the same inputs differ in the last bits, <= 9e-16); the ring sweep, the small-bond sweep and the
+  // one-wave sweeps add in a fixed order.  So the fused sweep is taken out of the selection (sets with a bond > 32 run the ring
+  // sweep: 518 instead of 412 ms on the headline set) and the order in which workgroups pull pairs no longer matters.
+  if (const char* v = std::getenv("QK_DETERMINISTIC"))
+    if (std::atoi(v) != 0) c->fused_path = 0, c->deterministic = true;
   if (const char* v = std::getenv("QK_FUSED_SPLIT")) c->fused_split = std::atoi(v) != 0;
   if (const char* v = std::getenv("QK_FUSED_WGS")) c->fused_wgs = std::max(0, std::min(2, std::atoi(v)));
   if (const char* v = std::getenv("QK_WGS_PER_CU")) c->wgs_per_cu = std::max(1, std::min(4, std::atoi(v)));

@@ -109,16 +109,16 @@ _SIGNATURES = [
     ("qk_comm_stats", C.c_int, [_P, C.c_int32, C.POINTER(QkStats), C.POINTER(C.c_double)]),
 ]
 EXPORTED_SYMBOLS = [s[0] for s in _SIGNATURES]
-# entry points of csrc/qk_lab.h: only the lab library (libqklab.so, loaded by tools/ via use_lab_library()) has them
+# entry points of lab/qk_lab.h: only the lab library (lab/libqklab.so, loaded by lab/tools via use_lab_library()) has them
 _LAB_SIGNATURES = [
     ("qk_debug_profile", C.c_int, [_P, _P]),
     ("qk_debug_mma_bench", C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double)]),
 ]
-LAB_LIB_PATH = os.path.join(_HERE, "libqklab.so")
+LAB_LIB_PATH = os.path.join(os.path.dirname(_HERE), "lab", "libqklab.so")
 
 
 def use_lab_library(path=None):
-    """tools/ only: load the lab library (experimental kernels, QK_VARIANT, instrumented builds) instead of the
+    """lab/tools only: load the lab library (experimental kernels, QK_VARIANT, instrumented builds) instead of the
     shipped one.  Must be called before the first use of the engine."""
     global LIB_PATH
     if _lib is not None:

@@ -720,3 +720,29 @@ def test_complex64_storage_wave_sweep(gpu_ctx, monkeypatch):
         z_small = ctx1.overlaps(fx, fy)
         assert "small" in ctx1.stats()["kernel_name"]
     assert np.abs(z_small - z32).max() < F32_TOL
+
+
+def test_deterministic_mode_is_bit_reproducible(built, monkeypatch):
+    """QK_DETERMINISTIC=1 takes the site-fused sweep (LDS atomics in arrival order) out of the selection: two Grams of the same
+    ragged set are bit-identical, launch after launch and context after context, and agree with the default path to rounding."""
+    import qml_cutensornet_amd as Q
+    from oracle import restatement as R
+    from qml_cutensornet_amd import engine
+
+    rng = np.random.default_rng(41)
+    n = 24
+    xs = [Q.random_mps(n, _ragged_profile(rng, n, c), rng) for c in (90, 140, 40, 70, 33, 120, 64, 18)]
+    K_ref = R.gram_from_mps([m.tensors for m in xs])
+    with engine.context(0) as ctx, ctx.upload(xs) as dx:
+        K_default = ctx.gram(dx)
+        assert "fused" in ctx.stats()["kernel_name"]
+    monkeypatch.setenv("QK_DETERMINISTIC", "1")
+    runs = []
+    for _ in range(2):
+        with engine.context(0) as ctx, ctx.upload(xs) as dx:
+            runs.append(ctx.gram(dx))
+            runs.append(ctx.gram(dx))
+            assert "fused" not in ctx.stats()["kernel_name"]
+    for K in runs[1:]:
+        assert np.array_equal(K, runs[0])
+    assert np.abs(runs[0] - K_ref).max() < TOL and np.abs(runs[0] - K_default).max() < 1e-13
