@@ -78,7 +78,7 @@ typedef struct qk_stats {
   int64_t second_pairs;
   double second_flops, second_padded_flops, second_bytes;
   double second_ms;     /* device time of the second launch (kernel_ms covers both)    */
-  int32_t second_kernel; /* QK_KERNEL_FUSED2, or QK_KERNEL_NONE                          */
+  int32_t second_kernel; /* QK_KERNEL_FUSED2; QK_KERNEL_WAVE2 for a mixed set (its pairs of two small states); or QK_KERNEL_NONE */
   int32_t queues;        /* device work queues of the launch: 8 per class of pairs (one per XCD), 1 = one list */
   /* Tail accounting from device clocks (first workgroup start, first and last workgroup exit per launch): the share of a
    * launch's duration during which the chip was draining -- some workgroups had run out of work, the last one had not.
@@ -181,9 +181,12 @@ int64_t qk_plan_total_pairs(const qk_plan* plan);     /* all ranks              
 int64_t qk_plan_max_pairs_per_rank(const qk_plan* plan);
 const int32_t* qk_plan_pairs(const qk_plan* plan);    /* [num_pairs][2] = (i, j), host  */
 int qk_plan_stats(const qk_plan* plan, qk_stats* out); /* algorithmic flops/bytes of this rank's share */
-/* Pairs [qk_plan_first_run, num_pairs) are the pairs with >= QK_PLAN_SPLIT (environment, default 0.75) of their padded work in
- * sites that fit the site-fused kernel's smaller LDS buffer; qk_gram_values sweeps the two runs with the kernel's two shapes
- * (one launch each).  == num_pairs when the plan holds (nearly) one class only.                                          */
+/* Pairs [qk_plan_first_run, num_pairs) are the SECOND RUN of the list, swept by its own launch right behind the first:
+ *   - a mixed set (states with every bond <= 32 next to larger ones, at least 64 pairs of two small states): those small-small
+ *     pairs, for the one-pair-per-wavefront sweep -- kernel choice is per PAIR, one large state does not drag the rest along;
+ *   - otherwise the pairs with >= QK_PLAN_SPLIT (environment, default 0.75) of their padded work in sites that fit the site-fused
+ *     kernel's smaller LDS buffer, for its two-workgroups-per-CU shape.
+ * == num_pairs when the plan holds (nearly) one class only.                                                              */
 int64_t qk_plan_first_run(const qk_plan* plan);
 /* XCD-aware work queues (default plans; QK_PLAN_XCD=0 in the environment or an explicit `block` gives the flat cost-ordered
  * list).  The states are sorted by weight, the Gram is cut into tiles of QK_PLAN_TILE x QK_PLAN_TILE (default 8 x 8) pairs in

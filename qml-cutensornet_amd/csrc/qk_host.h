@@ -78,6 +78,7 @@ struct qk_plan {
   int64_t n_first = 0;     // pairs [n_first, end) are the class whose sites fit the fused sweep's smaller LDS buffer (== number of pairs: no split)
   int nq = 1;                 // device work queues: 1 = one list; 16 = two classes of pairs x 8 XCD queues (the second class may be empty)
   int64_t qstart[17] = {0};   // queue s = pairs [qstart[s], qstart[s + 1]) of this rank's list; queues 8..15 = the class-1 run
+  bool second_wave2 = false;  // the second run holds the pairs of two states whose bonds are all <= 32: swept by the one-wave kernel (mixed sets)
   double fit_two = 1.0;  // share of this rank's padded work in sites whose X and X' fit the fused sweep's smaller LDS buffer
   // lazily uploaded copy
   qk_ctx* up_ctx = nullptr;

@@ -304,8 +304,25 @@ static void plan_tiled(qk_plan* p, const int n_sites, const int nx, const int32_
       flops += it.f, padded += it.fp, bytes += it.by, fit_two += it.ft;
       if (it.fp > 0 && it.ft >= split * it.fp) small_work += it.fp;
     }
-  const bool two_classes = !(small_work < 0.05 * padded || small_work > 0.95 * padded);
-  auto cls_of = [&](const Item& it) { return (two_classes && it.fp > 0 && it.ft >= split * it.fp) ? 1 : 0; };
+  // A MIXED set -- some states with every bond <= 32 next to larger ones -- keeps its small-small pairs on the one-wave sweep
+  // (2 x 2 register tiles, 2-3 x faster per such pair than the multi-wave kernels): they form the second run instead, swept by
+  // qk_sweep_wave2_kernel right behind the fused launch.  (A set whose bonds are all <= 32 runs that kernel anyway.)
+  auto max_pad_of = [&](const int n, const int32_t* dims) {
+    std::vector<int> mp((size_t)n, 0);
+    for (int s_ = 0; s_ < n; ++s_)
+      for (int k = 0; k <= n_sites; ++k) mp[(size_t)s_] = std::max(mp[(size_t)s_], pad16(dims[(int64_t)s_ * stride + k]));
+    return mp;
+  };
+  const std::vector<int> mpx = max_pad_of(nx, x_dims), mpy = sym ? mpx : max_pad_of(ny, y_dims);
+  const bool any_large = *std::max_element(mpx.begin(), mpx.end()) > 32 || *std::max_element(mpy.begin(), mpy.end()) > 32;
+  auto small_pair = [&](const Item& it) { return mpx[(size_t)it.i] <= 32 && mpy[(size_t)it.j] <= 32; };
+  int64_t n_small_pairs = 0, n_mine = 0;
+  for (const int t : mine)
+    for (int64_t q = tiles[(size_t)t].start; q < tiles[(size_t)t].start + tiles[(size_t)t].count; ++q) n_small_pairs += small_pair(items[(size_t)q]) ? 1 : 0, ++n_mine;
+  const bool mixed = any_large && n_small_pairs >= std::max<int64_t>(64, n_mine / 50) && n_small_pairs < n_mine && !std::getenv("QK_PLAN_NO_MIXED");
+  p->second_wave2 = mixed;
+  const bool two_classes = mixed || !(small_work < 0.05 * padded || small_work > 0.95 * padded);
+  auto cls_of = [&](const Item& it) { return mixed ? (small_pair(it) ? 1 : 0) : ((two_classes && it.fp > 0 && it.ft >= split * it.fp) ? 1 : 0); };
   p->pairs.clear(), p->groups.clear();
   p->second = qk_stats{};
   p->nq = QK_NQ_MAX;
@@ -989,7 +1006,9 @@ extern "C" int qk_gram_values(qk_ctx* c, const qk_mps_set* xs, const qk_mps_set*
   const bool can_two = max_pad <= QKF_XCAP_TWO / TILE && (size_t)QKF_XCAP_TWO * 16 + lds_meta <= 80 * 1024;
   const bool fused = fused_ok && (can_one || can_two);
   // two runs of pairs, two shapes (see qk_plan_create): only when the launch is free to choose its shape
-  const bool two_runs = fused && can_one && can_two && c->fused_wgs == 0 && c->fused_split && plan->n_first > 0 && plan->n_first < np;
+  const bool two_runs = fused && can_one && can_two && c->fused_wgs == 0 && c->fused_split && !plan->second_wave2 && plan->n_first > 0 && plan->n_first < np;
+  // a mixed set: the plan's second run holds the pairs of two small states (every bond <= 32) for the one-wave sweep
+  const bool mixed = fused && plan->second_wave2 && c->wave2_path && c->wave2_ring && plan->n_first > 0 && plan->n_first < np;
   const bool fused_two = fused && can_two && !two_runs && (!can_one || c->fused_wgs == 2 || (c->fused_wgs == 0 && plan->fit_two >= 0.75));
   const size_t lds_fused = (size_t)(fused_two ? QKF_XCAP_TWO : QKF_XCAP_ONE) * 16 + lds_meta;
   const int grid = (int)std::min<long long>(units, (long long)(fused ? (fused_two ? 2 : 1) : c->wgs_per_cu) * c->num_cus);
@@ -1081,7 +1100,26 @@ extern "C" int qk_gram_values(qk_ctx* c, const qk_mps_set* xs, const qk_mps_set*
     a.nq = plan->nq, c->last.queues = plan->nq > 1 ? 8 : 1, c->tail_pending = true;
     // the dual form (pairs of tiles per wave: half the A and X fragments per matrix instruction) against single tiles, same box:
     // uniform bonds 48 / 64 / 96 / 128 / 256: +2 / +4 / +7 / +12 / +19 %; first run of the headline set's split sweep: 255 against 264 ms
-    if (fused_two) QKF_KERNEL_TWO<<<dim3(grid), dim3(64 * QKF_TWO_NW), lds_fused, c->stream>>>(a);
+    if (mixed) {
+      SweepArgs a1 = a, a2 = a;
+      a1.npairs = plan->n_first;
+      a2.pairs = a.pairs + 2 * plan->n_first, a2.npairs = np - plan->n_first;
+      a2.values = a.values + plan->n_first, a2.z = a.z ? a.z + 2 * plan->n_first : nullptr;
+      a2.counter = c->counter + 8 * QK_QSTRIDE, a2.tail = tail + 2;
+      if (plan->nq > 1) {
+        a1.nq = a2.nq = 8;
+        for (int s_ = 0; s_ <= 8; ++s_) a2.qstart[s_] = plan->qstart[8 + s_] - plan->n_first;
+      }
+      const unsigned g1 = (unsigned)std::min<long long>(a1.npairs, (long long)(fused_two ? 2 : 1) * c->num_cus);
+      if (fused_two) QKF_KERNEL_TWO<<<dim3(g1), dim3(64 * QKF_TWO_NW), lds_fused, c->stream>>>(a1);
+      else if (dual) QKF_KERNEL_DUAL<<<dim3(g1), dim3(64 * QKF_DUAL_NW), lds_fused, c->stream>>>(a1);
+      else QKF_KERNEL_ONE<<<dim3(g1), dim3(64 * QKF_ONE_NW), lds_fused, c->stream>>>(a1);
+      HIP_TRY(hipEventRecord(c->ev_mid, c->stream));
+      qk_sweep_wave2_kernel<3, double><<<dim3((unsigned)std::min<long long>(a2.npairs, 8ll * c->num_cus)), dim3(64), 0, c->stream>>>(a2);
+      c->last.second_pairs = plan->second.pairs, c->last.second_flops = plan->second.flops, c->last.second_padded_flops = plan->second.padded_flops;
+      c->last.second_bytes = plan->second.bytes, c->last.second_kernel = QK_KERNEL_WAVE2;
+      c->split_pending = true;
+    } else if (fused_two) QKF_KERNEL_TWO<<<dim3(grid), dim3(64 * QKF_TWO_NW), lds_fused, c->stream>>>(a);
     else if (dual && !split) QKF_KERNEL_DUAL<<<dim3(grid), dim3(64 * QKF_DUAL_NW), lds_fused, c->stream>>>(a);
     else if (split) {
       // the plan lists the pairs whose sites fit the smaller LDS buffer behind the others: one 12-wave workgroup per CU for

@@ -731,7 +731,7 @@ def test_deterministic_mode_is_bit_reproducible(built, monkeypatch):
 
     rng = np.random.default_rng(41)
     n = 24
-    xs = [Q.random_mps(n, _ragged_profile(rng, n, c), rng) for c in (90, 140, 40, 70, 33, 120, 64, 18)]
+    xs = [Q.random_mps(n, [min(2 ** min(k, n - k), c) for k in range(n + 1)], rng) for c in (90, 140, 40, 70, 33, 120, 64, 18)]
     K_ref = R.gram_from_mps([m.tensors for m in xs])
     with engine.context(0) as ctx, ctx.upload(xs) as dx:
         K_default = ctx.gram(dx)
@@ -746,3 +746,32 @@ def test_deterministic_mode_is_bit_reproducible(built, monkeypatch):
     for K in runs[1:]:
         assert np.array_equal(K, runs[0])
     assert np.abs(runs[0] - K_ref).max() < TOL and np.abs(runs[0] - K_default).max() < 1e-13
+
+
+def test_mixed_set_keeps_small_pairs_on_the_one_wave_sweep(gpu_ctx, monkeypatch):
+    """A set of small states (every bond <= 32) with a few large ones: the plan lists the small-small pairs as its second run and the
+    engine sweeps them with the one-wave kernel right behind the fused launch -- one large state no longer drags every pair of the
+    set onto the multi-wave kernels.  Same Gram as the oracle and as the unmixed plan."""
+    import qml_cutensornet_amd as Q
+    from oracle import restatement as R
+    from qml_cutensornet_amd import engine
+
+    rng = np.random.default_rng(77)
+    n = 20
+    caps = [30, 24, 17, 32, 9, 28, 31, 12, 20, 26, 16, 29, 90, 140, 60]
+    xs = [Q.random_mps(n, [min(2 ** min(k, n - k), c) for k in range(n + 1)], rng) for c in caps]
+    K_ref = R.gram_from_mps([m.tensors for m in xs])
+    plan = engine.Plan(np.array([m.bond_dims() for m in xs]))
+    small = {i for i, c in enumerate(caps) if c <= 32}
+    pr, first = plan.pairs(), plan.first_run
+    assert len(pr) - first == len(small) * (len(small) + 1) // 2
+    assert all((i in small and j in small) == (t >= first) for t, (i, j) in enumerate(pr.tolist()))
+    plan.close()
+    with gpu_ctx.upload(xs) as dx:
+        K = gpu_ctx.gram(dx)
+        st = gpu_ctx.stats()
+        assert "fused" in st["kernel_name"] and "wave2" in st["second_kernel_name"] and st["second_pairs"] == len(pr) - first and st["second_ms"] > 0
+        monkeypatch.setenv("QK_PLAN_NO_MIXED", "1")
+        K_plain = gpu_ctx.gram(dx)
+        assert "wave2" not in gpu_ctx.stats()["second_kernel_name"]
+    assert np.abs(K - K_ref).max() < TOL and np.array_equal(K, K.T) and np.abs(K - K_plain).max() < 1e-13
