@@ -136,19 +136,28 @@ def device_build_leg(ctx, ansatz, X, states, log_):
     """The input producer on the device (SURVEY 8f N1): every circuit of the data set in ONE launch of the device builder, timed;
     the Gram of the device-built set is returned so that the caller can compare it with the Gram of the host-built states
     (the ones the timed steps run on).  Untimed region."""
+    from qml_cutensornet_amd.gpu_backend.kernel_state_ansatz import SMALL_BOND_CAP, _expect_small_bonds
+
     circs = [ansatz.circuit_for_data(x) for x in X]
-    cap = int(os.environ.get("QK_BUILDER_MAX_BOND", "320"))
+    big = int(os.environ.get("QK_BUILDER_MAX_BOND", "320"))
+    caps = [SMALL_BOND_CAP, big] if _expect_small_bonds(ansatz, circs) else [big]  # build_kernel_matrix's escalation: the small-bond shape first where it is expected to do
     t0 = time.perf_counter()
-    try:
-        dset, info = ctx.build_mps_set(circs, max_bond=cap)
-    except Exception as exc:  # noqa: BLE001 - reported; the timed Gram does not depend on it
-        log_(f"device builder failed: {exc}")
-        return {"error": str(exc)}, None
+    dset = info = None
+    for cap in caps:
+        try:
+            dset, info = ctx.build_mps_set(circs, max_bond=cap)
+            break
+        except Exception as exc:  # noqa: BLE001 - reported; the timed Gram does not depend on it
+            log_(f"device builder at bonds <= {cap}: {exc}")
+            err = str(exc)
+    if dset is None:
+        return {"error": err}, None
     wall = time.perf_counter() - t0
     host_dims = np.array([m.bond_dims() for m in states])
     differ = int((info["dims"] != host_dims).any(axis=1).sum())
     K = ctx.gram(dset)
     dset.close()
+    ctx.trim()  # the builder's arena and workspace (tens of GB) go back before the timed Gram
     return {"device_kernel_s": info["kernel_ms"] / 1e3, "device_wall_s": wall, "max_bond_cap": cap, "states_whose_bonds_differ_from_host": differ,
             "largest_bond_difference": int(np.abs(info["dims"] - host_dims).max())}, K
 

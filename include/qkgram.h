@@ -115,6 +115,9 @@ int qk_ctx_destroy(qk_ctx* ctx);
 int qk_ctx_set_stream(qk_ctx* ctx, void* hip_stream);
 int qk_ctx_use_own_stream(qk_ctx* ctx);
 int qk_ctx_synchronize(qk_ctx* ctx);
+/* Release the device memory a context keeps between calls: the sweep's per-workgroup scratch and the device builder's arena and
+ * workspace (tens of GB at large bond caps; kept because allocating them costs seconds).  They come back on demand.          */
+int qk_ctx_trim(qk_ctx* ctx);
 
 /* ---- MPS sets ---------------------------------------------------------------
  * Upload n_states MPS of n_sites sites each.

@@ -171,7 +171,7 @@ extern "C" int qk_build_mps(qk_ctx* c, int32_t n_states, int32_t n_qubits, int32
   int* d_err = nullptr;
   int32_t* d_order = nullptr;
   auto release = [&]() {
-    (void)hipFree(arena), (void)hipFree(work), (void)hipFree(d_op), (void)hipFree(d_q0), (void)hipFree(d_alpha), (void)hipFree(d_fid), (void)hipFree(d_secs);
+    (void)hipFree(d_op), (void)hipFree(d_q0), (void)hipFree(d_alpha), (void)hipFree(d_fid), (void)hipFree(d_secs);
     (void)hipFree(d_dims), (void)hipFree(d_offs), (void)hipFree(d_ctr), (void)hipFree(d_err), (void)hipFree(d_order);
   };
 #define BUILD_TRY(expr)                                                                                   \
@@ -183,8 +183,24 @@ extern "C" int qk_build_mps(qk_ctx* c, int32_t n_states, int32_t n_qubits, int32
       return qk_fail(QK_EDEVICE, "qk_build_mps: %s failed: %s", #expr, hipGetErrorString(e_));            \
     }                                                                                                     \
   } while (0)
-  BUILD_TRY(hipMalloc(&arena, (size_t)grid * n_qubits * 2 * cap * cap * sizeof(cd)));
-  BUILD_TRY(hipMalloc(&work, (size_t)grid * (4 * wslot + wtab) * sizeof(cd)));
+  // the per-workgroup arena and workspace (tens of GB at large bond caps: allocating and releasing them costs seconds) stay with
+  // the context between calls -- build_kernel_matrix builds the X and the Y share one after the other -- and go with it
+  {
+    const size_t arena_b = (size_t)grid * n_qubits * 2 * cap * cap * sizeof(cd), work_b = (size_t)grid * (4 * wslot + wtab) * sizeof(cd);
+    if (c->build_arena_bytes < arena_b) {
+      if (c->build_arena) (void)hipFree(c->build_arena);
+      c->build_arena = nullptr, c->build_arena_bytes = 0;
+      BUILD_TRY(hipMalloc(&c->build_arena, arena_b));
+      c->build_arena_bytes = arena_b;
+    }
+    if (c->build_work_bytes < work_b) {
+      if (c->build_work) (void)hipFree(c->build_work);
+      c->build_work = nullptr, c->build_work_bytes = 0;
+      BUILD_TRY(hipMalloc(&c->build_work, work_b));
+      c->build_work_bytes = work_b;
+    }
+    arena = static_cast<cd*>(c->build_arena), work = static_cast<cd*>(c->build_work);
+  }
   BUILD_TRY(hipMalloc(&heap, heap_cap * sizeof(cd)));
   BUILD_TRY(hipMalloc(&d_op, std::max(1, n_ops)));
   BUILD_TRY(hipMalloc(&d_q0, (size_t)std::max(1, n_ops) * sizeof(int32_t)));
@@ -194,14 +210,14 @@ extern "C" int qk_build_mps(qk_ctx* c, int32_t n_states, int32_t n_qubits, int32
   BUILD_TRY(hipMalloc(&d_dims, (size_t)n_states * (n_qubits + 1) * sizeof(int32_t)));
   BUILD_TRY(hipMalloc(&d_offs, (size_t)n_states * sizeof(long long)));
   BUILD_TRY(hipMalloc(&d_ctr, 2 * sizeof(unsigned long long)));
-  BUILD_TRY(hipMalloc(&d_err, 24 * sizeof(int)));
+  BUILD_TRY(hipMalloc(&d_err, 32 * sizeof(int)));
   if (n_ops > 0) {
     BUILD_TRY(hipMemcpyAsync(d_op, op, n_ops, hipMemcpyHostToDevice, c->stream));
     BUILD_TRY(hipMemcpyAsync(d_q0, q0, (size_t)n_ops * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
     BUILD_TRY(hipMemcpyAsync(d_alpha, alpha, (size_t)n_states * n_ops * sizeof(double), hipMemcpyHostToDevice, c->stream));
   }
   BUILD_TRY(hipMemsetAsync(d_ctr, 0, 2 * sizeof(unsigned long long), c->stream));
-  BUILD_TRY(hipMemsetAsync(d_err, 0, 24 * sizeof(int), c->stream));
+  BUILD_TRY(hipMemsetAsync(d_err, 0, 32 * sizeof(int), c->stream));
   // Queue order: longest expected first.  The cost of a state grows with its bonds, and those with the entangling power
   // of its XXPhase gates, sin^2(pi alpha) summed over the gates -- a cheap proxy that keeps the tail of the launch short.
   std::vector<int32_t> order(n_states);
@@ -242,7 +258,7 @@ extern "C" int qk_build_mps(qk_ctx* c, int32_t n_states, int32_t n_qubits, int32
   b->fidelity.resize(n_states);
   b->offsets.resize(n_states);
   std::vector<long long> offs(n_states);
-  int errv[24] = {0};
+  int errv[32] = {0};
   unsigned long long ctr[2] = {0, 0};
   hipError_t e = hipStreamSynchronize(c->stream);
   if (e == hipSuccess) e = hipMemcpy(b->dims.data(), d_dims, b->dims.size() * sizeof(int32_t), hipMemcpyDeviceToHost);
@@ -272,6 +288,7 @@ extern "C" int qk_build_mps(qk_ctx* c, int32_t n_states, int32_t n_qubits, int32
   if (std::getenv("QK_BUILD_DEBUG") && errv[7]) {
     unsigned long long tk[5];
     for (int i = 0; i < 5; ++i) std::memcpy(&tk[i], errv + 14 + 2 * i, 8);
+    std::fprintf(stderr, "[qk_build_mps] %d centre moves of large sites by Gram-Schmidt twice (no sweeps)\n", errv[24]);
     std::fprintf(stderr, "[qk_build_mps] %d preconditioned block factorisations: %.3f s of workgroup time (sort+copy %.1f %%, Gram-Schmidt %.1f %%, sweeps %.1f %%, V and W = A V %.1f %%)\n", errv[7],
                  (double)tk[0] / 1e8, 100.0 * tk[1] / std::max(1ull, tk[0]), 100.0 * tk[2] / std::max(1ull, tk[0]), 100.0 * tk[3] / std::max(1ull, tk[0]), 100.0 * tk[4] / std::max(1ull, tk[0]));
   }
@@ -405,9 +422,9 @@ extern "C" int qk_debug_jacobi_precond(qk_ctx* c, int32_t p, int32_t q, double* 
   HIP_TRY(hipMalloc(&b.dL, lrows * qpad * sizeof(cd)));
   HIP_TRY(hipMalloc(&b.dSig, (size_t)q * sizeof(double)));
   HIP_TRY(hipMalloc(&b.dO, (size_t)q * sizeof(int)));
-  HIP_TRY(hipMalloc(&b.dE, 24 * sizeof(int)));
+  HIP_TRY(hipMalloc(&b.dE, 32 * sizeof(int)));
   HIP_TRY(hipMalloc(&b.dC, (qpad / 8) * (qpad / 8) * sizeof(int)));
-  HIP_TRY(hipMemset(b.dE, 0, 24 * sizeof(int)));
+  HIP_TRY(hipMemset(b.dE, 0, 32 * sizeof(int)));
   HIP_TRY(hipMemcpy(b.dA, a_inout, (size_t)p * q * sizeof(cd), hipMemcpyHostToDevice));
   const size_t lds_head = (size_t)(((q * 12 + 15) / 16) * 2 + 2) * sizeof(double);
   const bool wide = std::getenv("QK_BUILD_WGS") && std::atoi(std::getenv("QK_BUILD_WGS")) <= 1;  // the 512-thread variant of the builder
@@ -429,7 +446,7 @@ extern "C" int qk_debug_jacobi_precond(qk_ctx* c, int32_t p, int32_t q, double* 
   HIP_TRY(hipMemcpy(v_out, b.dV, (size_t)q * q * sizeof(cd), hipMemcpyDeviceToHost));
   HIP_TRY(hipMemcpy(sig_out, b.dSig, (size_t)q * sizeof(double), hipMemcpyDeviceToHost));
   HIP_TRY(hipMemcpy(ord_out, b.dO, (size_t)q * sizeof(int), hipMemcpyDeviceToHost));
-  int errv[24] = {0};
+  int errv[32] = {0};
   HIP_TRY(hipMemcpy(errv, b.dE, sizeof errv, hipMemcpyDeviceToHost));
   if (stats_out) {  // [0] sweeps, then 100 MHz ticks (low words): [1] all, [2] sort + copy, [3] Gram-Schmidt, [4] sweeps, [5] V and W = A V
     stats_out[0] = errv[2];
@@ -450,8 +467,8 @@ extern "C" int qk_debug_jacobi(qk_ctx* c, int32_t p, int32_t q, double* a_inout,
   HIP_TRY(hipMalloc(&dV, (size_t)q * q * sizeof(cd)));
   HIP_TRY(hipMalloc(&dS, (size_t)q * sizeof(double)));
   HIP_TRY(hipMalloc(&dO, (size_t)q * sizeof(int)));
-  HIP_TRY(hipMalloc(&dE, 24 * sizeof(int)));
-  HIP_TRY(hipMemset(dE, 0, 24 * sizeof(int)));
+  HIP_TRY(hipMalloc(&dE, 32 * sizeof(int)));
+  HIP_TRY(hipMemset(dE, 0, 32 * sizeof(int)));
   HIP_TRY(hipMemcpy(dA, a_inout, (size_t)p * q * sizeof(cd), hipMemcpyHostToDevice));
   qkb256::qk_jacobi_kernel<<<dim3(1), dim3(256), (size_t)q * (sizeof(double) + sizeof(int)) + 16, c->stream>>>(dA, p, q, dV, dS, dO, dE);
   HIP_TRY(hipGetLastError());

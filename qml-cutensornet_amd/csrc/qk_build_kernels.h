@@ -588,13 +588,13 @@ __device__ __forceinline__ double wave_sum_f64(double v) {
 // into the block layout LB (column k of L in block k / 8, rows of 8 complex).  The panel lives in LDS (`lds`: nbp * p complex): it is
 // orthogonalised there and then projected out of every trailing column -- one column per wavefront at a time, the column in
 // registers (RR rows per lane), read from and written to memory once per panel.  Q is never needed, so the panel is not written back.
-template <int RR>
-__device__ void mgs_panels(cd* S, const int p, const int q, const int nbp, cd* LB, const long lstride, cd* lds) {
+// put_l(j, k, re, im) receives r_kj (k <= j); KEEP_Q: the orthonormalised panel is written back, so that S ends as Q.
+template <int RR, bool KEEP_Q, typename PUT>
+__device__ void mgs_panels(cd* S, const int p, const int q, const int nbp, const PUT put_l, cd* lds) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   lds_cd_ptr QP = (lds_cd_ptr)lds;  // QP[kk * p + i]
   __shared__ double nrm_s[MGS_NB];
-  auto put_l = [&](const int j, const int k, const double re, const double im) __attribute__((always_inline)) { LB[(long)(k >> 3) * lstride + (long)j * NBC + (k & 7)] = cd{re, -im}; };
   for (int k0 = 0; k0 < q; k0 += nbp) {
     const int kn = min(nbp, q - k0);
     for (int e = tid; e < kn * p; e += BT) QP[e] = S[(long)k0 * p + e];
@@ -632,7 +632,9 @@ __device__ void mgs_panels(cd* S, const int p, const int q, const int nbp, cd* L
       const double inv = nrm_s[kk];
       for (int i = lane; i < p; i += 64) {
         const cd x = QP[kk * p + i];
-        QP[kk * p + i] = cd{x.x * inv, x.y * inv};
+        const cd y = cd{x.x * inv, x.y * inv};
+        QP[kk * p + i] = y;
+        if (KEEP_Q) S[(long)(k0 + kk) * p + i] = y;
       }
     }
     __syncthreads();
@@ -728,11 +730,12 @@ __device__ __noinline__ void jacobi_precond(cd* A, const long rs, const long cs,
   // ---- 2. panel MGS: L[j][k] = conj(r_kj)
   {
     const int nbp = max(1, min(MGS_NB, lds_elems / max(p, 1)));  // columns of a panel: what the LDS working set holds
-    if (p <= 128) mgs_panels<2>(S, p, q, nbp, LB, lstride, lds);
-    else if (p <= 256) mgs_panels<4>(S, p, q, nbp, LB, lstride, lds);
-    else if (p <= 512) mgs_panels<8>(S, p, q, nbp, LB, lstride, lds);
-    else if (p <= 768) mgs_panels<12>(S, p, q, nbp, LB, lstride, lds);
-    else mgs_panels<16>(S, p, q, nbp, LB, lstride, lds);
+    auto put_l = [=](const int j, const int k, const double re, const double im) __attribute__((always_inline)) { LB[(long)(k >> 3) * lstride + (long)j * NBC + (k & 7)] = cd{re, -im}; };
+    if (p <= 128) mgs_panels<2, false>(S, p, q, nbp, put_l, lds);
+    else if (p <= 256) mgs_panels<4, false>(S, p, q, nbp, put_l, lds);
+    else if (p <= 512) mgs_panels<8, false>(S, p, q, nbp, put_l, lds);
+    else if (p <= 768) mgs_panels<12, false>(S, p, q, nbp, put_l, lds);
+    else mgs_panels<16, false>(S, p, q, nbp, put_l, lds);
   }
   const long long t_mgs = wall_clock64();
   // ---- 3. numerical rank: the last column of L (row of R) that carries weight
@@ -816,6 +819,31 @@ __device__ __noinline__ void jacobi_precond(cd* A, const long rs, const long cs,
 // L2 round trip.  Results are copied back to the global A (same strides) and to V (row-major, ld q).
 // (Inlined into the kernel so that the kernel's register budget -- MINWG workgroups per CU -- governs it; the variant that
 // keeps 8 rows per lane in registers exists only at 2 workgroups per CU.)
+// QR for the centre moves of large sites: A (p x q, element (i, j) at A[i * rs + j * cs]) = Q R with Q orthonormal to working
+// precision -- Gram-Schmidt TWICE ("twice is enough": the second pass removes what the first, on a centre tensor whose singular
+// values span many orders of magnitude, leaves of the earlier columns in the later ones) -- and R = R2 R1.  No sweeps at all: a
+// centre move needs an isometry and a triangle, not singular values; the bond does not change (what the host builder's QR does).
+// Out: S = Q (column-major, p x q); R1, R2 (row-major q x q, upper triangles; the strict lower parts are zeroed).
+__device__ void mgs2_qr(const cd* A, const long rs, const long cs, const int p, const int q, cd* S, cd* R1, cd* R2, cd* lds, const int lds_elems) {
+  const int tid = threadIdx.x;
+  for (long e = tid; e < (long)p * q; e += BT) {
+    const int i = (int)(e / q), jc = (int)(e - (long)i * q);
+    S[(long)jc * p + i] = A[i * rs + jc * cs];
+  }
+  for (long e = tid; e < (long)q * q; e += BT) R1[e] = cd{0.0, 0.0}, R2[e] = cd{0.0, 0.0};
+  __syncthreads();
+  const int nbp = max(1, min(MGS_NB, lds_elems / max(p, 1)));
+  for (int pass = 0; pass < 2; ++pass) {
+    cd* const R = pass == 0 ? R1 : R2;
+    auto put = [=](const int j, const int k, const double re, const double im) __attribute__((always_inline)) { R[(long)k * q + j] = cd{re, im}; };
+    if (p <= 128) mgs_panels<2, true>(S, p, q, nbp, put, lds);
+    else if (p <= 256) mgs_panels<4, true>(S, p, q, nbp, put, lds);
+    else if (p <= 512) mgs_panels<8, true>(S, p, q, nbp, put, lds);
+    else if (p <= 768) mgs_panels<12, true>(S, p, q, nbp, put, lds);
+    else mgs_panels<16, true>(S, p, q, nbp, put, lds);
+  }
+}
+
 constexpr int g_precond_from = 48;  // columns from which a factorisation takes the preconditioned block path
 template <int MINWG>
 __device__ __forceinline__ void jacobi_auto(cd* A, const long rs, const long cs, const int p, const int q, cd* V, double* sig, int* ord, WgShared* sh,
@@ -1027,6 +1055,20 @@ __global__ __launch_bounds__(BT, MINWG) void qk_build_kernel(const BuildArgs g) 
         cd* u = sites + (centre + 1) * slot;
         const int l = dims[centre], r = dims[centre + 1], r2 = dims[centre + 2];
         const int m = 2 * l;
+        if (MINWG <= 2 && LBUF && r >= g_precond_from && r <= m && m <= 64 * MGS_R) {
+          // a large site: t = Q R by Gram-Schmidt twice, u <- R2 (R1 u); the bond keeps its size
+          mgs2_qr(t, r, 1, m, r, TMP, LBUF, VV, jl, g.jl_elems);
+          if (tid == 0) atomicAdd(g.error + 24, 1);
+          wg_gemm<false, false>(TH, r, 2 * r2, r, LBUF, r, 1, u, 2 * r2, 1);
+          wg_gemm<false, false>(u, r, 2 * r2, r, VV, r, 1, TH, 2 * r2, 1);
+          for (long e = tid; e < (long)m * r; e += BT) {
+            const int row = (int)(e / r), c = (int)(e - (long)row * r);
+            t[e] = TMP[(long)c * m + row];
+          }
+          __syncthreads();
+          ++centre;
+          continue;
+        }
         jacobi_auto<MINWG>(t, r, 1, m, r, VV, sig, ord, &sh, g.error, jl, g.jl_elems, TMP, LBUF, wslot);
         if (tid == 0) {
           int k = 0;
@@ -1058,6 +1100,17 @@ __global__ __launch_bounds__(BT, MINWG) void qk_build_kernel(const BuildArgs g) 
         const int l = dims[centre], r = dims[centre + 1], l0 = dims[centre - 1];
         const int w = 2 * r;
         // A(i = (p, c), j = a) = t[a][i]: rs = 1, cs = w
+        if (MINWG <= 2 && LBUF && l >= g_precond_from && l <= w && w <= 64 * MGS_R) {
+          // a large site: t^T = Q R by Gram-Schmidt twice: t <- Q^T, d <- d R^T = (d R1^T) R2^T ... in the order R = R2 R1: d R^T = (d R1^T) R2^T
+          mgs2_qr(t, 1, w, w, l, TMP, LBUF, VV, jl, g.jl_elems);
+          if (tid == 0) atomicAdd(g.error + 24, 1);
+          wg_gemm<false, false>(TH, 2 * l0, l, l, d, l, 1, LBUF, 1, l);  // B(a, jj) = R1[jj][a]
+          wg_gemm<false, false>(d, 2 * l0, l, l, TH, l, 1, VV, 1, l);    // B(a, jj) = R2[jj][a]
+          for (long e = tid; e < (long)l * w; e += BT) t[e] = TMP[e];     // t'[jj][i] = Q(i, jj): Q's column jj, contiguous in S
+          __syncthreads();
+          --centre;
+          continue;
+        }
         jacobi_auto<MINWG>(t, 1, w, w, l, VV, sig, ord, &sh, g.error, jl, g.jl_elems, TMP, LBUF, wslot);
         if (tid == 0) {
           int k = 0;

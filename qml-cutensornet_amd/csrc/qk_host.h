@@ -49,6 +49,11 @@ struct qk_ctx {
   bool deterministic = false;  // QK_DETERMINISTIC=1: only kernels that add in a fixed order (no LDS atomics)
   int fused_path = 1;      // fp64 sets with a bond > 32 use the site-fused sweep (QK_FUSED=0: ring sweep instead; 2: also for bonds 17..32)
   qk_stats last{};
+  // the device MPS builder's per-workgroup arena and workspace, kept between calls (qk_build.hip)
+  void* build_arena = nullptr;
+  size_t build_arena_bytes = 0;
+  void* build_work = nullptr;
+  size_t build_work_bytes = 0;
 };
 
 struct qk_mps_set {

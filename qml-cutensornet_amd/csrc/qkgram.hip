@@ -709,6 +709,8 @@ extern "C" int qk_ctx_destroy(qk_ctx* c) {
   (void)hipSetDevice(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   if (c->scratch) (void)hipFree(c->scratch);
+  if (c->build_arena) (void)hipFree(c->build_arena);
+  if (c->build_work) (void)hipFree(c->build_work);
   if (c->counter) (void)hipFree(c->counter);
   if (c->prof) (void)hipFree(c->prof);
   if (c->ev0) (void)hipEventDestroy(c->ev0);
@@ -716,6 +718,19 @@ extern "C" int qk_ctx_destroy(qk_ctx* c) {
   if (c->ev_mid) (void)hipEventDestroy(c->ev_mid);
   if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
   delete c;
+  return QK_OK;
+}
+
+extern "C" int qk_ctx_trim(qk_ctx* c) {
+  if (!c) return fail(QK_EINVAL, "qk_ctx_trim: null context");
+  HIP_TRY(hipSetDevice(c->device));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  if (c->scratch) (void)hipFree(c->scratch);
+  if (c->build_arena) (void)hipFree(c->build_arena);
+  if (c->build_work) (void)hipFree(c->build_work);
+  c->scratch = nullptr, c->scratch_bytes = 0;
+  c->build_arena = nullptr, c->build_arena_bytes = 0;
+  c->build_work = nullptr, c->build_work_bytes = 0;
   return QK_OK;
 }
 

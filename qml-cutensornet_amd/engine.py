@@ -63,6 +63,7 @@ _SIGNATURES = [
     ("qk_ctx_set_stream", C.c_int, [_P, _P]),
     ("qk_ctx_use_own_stream", C.c_int, [_P]),
     ("qk_ctx_synchronize", C.c_int, [_P]),
+    ("qk_ctx_trim", C.c_int, [_P]),
     ("qk_mps_set_create", C.c_int, [_P, C.c_int32, C.c_int32, _P, _P, C.c_int32, C.POINTER(_P)]),
     ("qk_mps_set_destroy", C.c_int, [_P]),
     ("qk_mps_set_info", C.c_int, [_P, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int64)]),
@@ -365,6 +366,10 @@ class Context:
 
     def synchronize(self):
         _check(lib().qk_ctx_synchronize(self._h), "qk_ctx_synchronize")
+
+    def trim(self):
+        """Release the device memory the context keeps between calls (sweep scratch, the device builder's arena and workspace)."""
+        _check(lib().qk_ctx_trim(self._h), "qk_ctx_trim")
 
     def debug_mma_bench(self, which, wgs_per_cu, reps=2000):
         out = C.c_double()

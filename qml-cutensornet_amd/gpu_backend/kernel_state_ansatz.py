@@ -145,6 +145,26 @@ def _auto_builder(circuits, host_workers):
     return "device" if m >= need else "host"
 
 
+SMALL_BOND_CAP = 64  # the device builder's cap for shares whose bonds are expected to stay small (_expect_small_bonds)
+
+
+def _expect_small_bonds(ansatz, circuits):
+    """Will the bonds of this share stay small (a few tens)?  Then the device builder's 256-thread shape with two workgroups per CU
+    (512 states in flight, most factorisations in LDS; bond cap 64) is the right one -- 100 qubits x 10 layers at gamma = 0.1
+    (final bonds <= 32, a few more in mid-circuit): 1000 states -- against one 512-thread workgroup per CU, the shape for bonds in
+    the hundreds (17.9 s for the same 1000 states).  Yes when the analytic bound 2^(distance x layers) says so, or when the
+    heaviest circuit's entangling weight is small (calibration: 40 qubits x 4 layers at gamma = 0.5, bonds 20-26, has w_max = 8.4;
+    gamma = 1 configurations start at w = 11 and reach bonds 60-250).  A wrong yes costs one short launch: a state that outgrows
+    the small cap is dropped at the gate where it does and the share is rebuilt with the large one."""
+    try:
+        dist_max = max((abs(int(b_) - int(a_)) for a_, b_ in ansatz.entanglement_map), default=0)
+        if 2 ** min(dist_max * int(ansatz.reps), int(ansatz.num_qubits) // 2) <= 64:
+            return True
+    except (AttributeError, TypeError, ValueError):
+        pass
+    return max(_entangling_weight(c) for c in circuits) <= 10.0
+
+
 def _simulate_share(ansatz, points, rank, n_procs, fidelity, is_root, label, device_id=0, host_workers=1, want_set=True):
     """This rank's slice of the data set (contiguous chunks of ceil(N/P), as ref :154,:171-174) -> (first index, the
     states as ONE packed device set -- ``None`` for an empty share --, seconds per state, fidelities).  ``want_set=False``
@@ -182,7 +202,14 @@ def _simulate_share(ansatz, points, rank, n_procs, fidelity, is_root, label, dev
                 _say(is_root, f"{label}: 100%")
                 return lo, ctx.upload(states), secs, [m.fidelity for m in states]
         try:
-            dset, states, binfo = ctx.build_share(circuits, fidelity, max_bond=cap, partial=partial, truncate=chi is not None)
+            dset = binfo = states = None
+            if chi is None and cap > SMALL_BOND_CAP and which != "hybrid" and _expect_small_bonds(ansatz, circuits):
+                dset, states, binfo = ctx.build_share(circuits, fidelity, max_bond=SMALL_BOND_CAP, partial=True)
+                if dset is None:  # some state outgrew the small cap after all: the whole share again, with the large one
+                    _say(is_root, f"{label}: {len(binfo['dropped'])} of {hi - lo} states outgrew bond {SMALL_BOND_CAP}; rebuilding with bonds up to {cap}")
+                    dset = binfo = states = None
+            if binfo is None:
+                dset, states, binfo = ctx.build_share(circuits, fidelity, max_bond=cap, partial=partial, truncate=chi is not None)
         except _engine.QkError as exc:
             if forced == "device":
                 raise

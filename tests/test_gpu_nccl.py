@@ -43,8 +43,21 @@ def _nccl_worker(port, q):
         job = GramJob(ctx, full, None, 1, 0, force_collective=True)  # all_gather_into_tensor of pairs and of values
         K = job.run()
         K_plain = ctx.gram(local)
-        q.put({"K": K, "K_plain": K_plain, "backend": dist.get_backend(), "states": [m.tensors for m in states], "exchange_s": secs})
-        job.close(), full.close(), local.close(), ctx.close()
+        # a LARGE share (hundreds of MB: a fill of the send buffer on another stream would still be running when the image copy
+        # lands -- the race the advisor found): the gathered image must be the local one, byte for byte
+        big_prof = [min(2 ** min(k, 24 - k), 160) for k in range(25)]
+        big = [Q.random_mps(24, big_prof, rng) for _ in range(40)]
+        big_local = ctx.upload(big)
+        big_full, _ = exchange_sets(TorchComm(), ctx, big_local, 0, len(big), force_collective=True)
+        n_a, ptr_a, dims_a, offs_a = big_local.image()
+        n_b, ptr_b, dims_b, offs_b = big_full.image()
+        img_a = torch.empty(n_a, dtype=torch.float64, device="cuda:0")
+        img_b = torch.empty(n_b, dtype=torch.float64, device="cuda:0")
+        big_local.copy_image(img_a.data_ptr(), n_a), big_full.copy_image(img_b.data_ptr(), n_b)
+        same_image = bool(torch.equal(img_a, img_b[:n_a])) and np.array_equal(dims_a, dims_b) and np.array_equal(offs_a, offs_b)
+        q.put({"K": K, "K_plain": K_plain, "backend": dist.get_backend(), "states": [m.tensors for m in states], "exchange_s": secs,
+               "big_image_mib": n_a * 8 / 2**20, "big_image_identical": same_image})
+        job.close(), full.close(), local.close(), big_full.close(), big_local.close(), ctx.close()
     finally:
         dist.destroy_process_group()
 
@@ -68,6 +81,7 @@ def test_one_rank_nccl_group_runs_the_collectives(built):
     # the gathered set and the gathered values change nothing (two launches of the fused sweep may differ in the last bit:
     # the sum over the tiles of a column is taken by LDS atomics, in arrival order)
     assert np.abs(res["K"] - res["K_plain"]).max() < 1e-14
+    assert res["big_image_mib"] > 200 and res["big_image_identical"]
 
 
 @pytest.mark.timeout(900)
