@@ -134,8 +134,9 @@ def _auto_builder(circuits, host_workers):
     workgroup -- 256 to 1024 in flight -- and a launch ends with its heaviest state, which takes about 2.5 x what one host
     core needs for it (60 qubits x 6 layers, gamma = 1: 4.3 s for the longest of 500 states, whose sum is 230-430 cpu-s).
     The host pool needs (states x mean cost) / workers.  With the heaviest state at (w_max / w_mean)^2 times the mean cost the
-    device wins from about 2.5 x workers x (w_max / w_mean)^2 states on: 500 states of that config (ratio 2.5) and 1000 of the
-    100-qubit gamma = 0.1 one (ratio 1.1) go to the device, a share of 63 of the former stays on 16 host cores."""
+    device wins from about 2.5 x workers x (w_max / w_mean)^2 states on -- at 16 workers: 137 states of that config (ratio 1.85),
+    250 of the 100-qubit gamma = 0.1 one (2.5), 180 of the 40-qubit x 4-layer one (2.1): the full data sets go to the device, an
+    eighth of the 60-qubit one (63 states) stays on the host cores."""
     m = len(circuits)
     if m == 0:
         return "host"
