@@ -276,6 +276,59 @@ __device__ void wg_gemm(cd* __restrict__ C, const int M, const int N, const int 
   __syncthreads();
 }
 
+// The same product on the f64 matrix cores for the large ones (theta = A_q A_{q+1}, W = A V, R x neighbour): C[M x N] (row-major,
+// ld N) = A B with A(i, k) at A[i * ars + k * acs], B(k, j) at B[k * brs + j * bcs].  One 16 x 16 tile of C per wavefront at a time,
+// 3M complex product on v_mfma_f64_16x16x4_f64, operands read straight into fragments (lane (q4, j) of k-step s: A(16 tm + j,
+// 4 s + q4) and B(4 s + q4, 16 tn + j); out-of-range elements read as zero).
+typedef double v4d_g __attribute__((ext_vector_type(4)));
+__device__ void wg_gemm_mfma(cd* __restrict__ C, const int M, const int N, const int K, const cd* __restrict__ A, const long ars, const long acs, const cd* __restrict__ B, const long brs,
+                             const long bcs) {
+  const int lane = threadIdx.x & 63, q4 = lane >> 4, j = lane & 15;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int tn_n = (N + 15) / 16, tiles = ((M + 15) / 16) * tn_n, nks = (K + 3) / 4;
+  for (int t = wave; t < tiles; t += BT / 64) {
+    const int tm = t / tn_n, tn = t - tm * tn_n;
+    const int ia = 16 * tm + j, jb = 16 * tn + j;
+    const bool va = ia < M, vb = jb < N;
+    const cd* pa = A + (long)min(ia, M - 1) * ars + (long)q4 * acs;
+    const cd* pb = B + (long)q4 * brs + (long)min(jb, N - 1) * bcs;
+    v4d_g p1 = {0, 0, 0, 0}, p2 = {0, 0, 0, 0}, p3 = {0, 0, 0, 0};
+    constexpr int PF = 4;
+    cd xa[PF], xb[PF];
+    auto ld = [&](const int s, cd& a, cd& b) __attribute__((always_inline)) {
+      const int k = 4 * s + q4;
+      const bool vk = k < K;
+      a = (va && vk) ? pa[(long)(4 * s) * acs] : cd{0.0, 0.0};
+      b = (vb && vk) ? pb[(long)(4 * s) * brs] : cd{0.0, 0.0};
+    };
+#pragma unroll
+    for (int i = 0; i < PF; ++i) {
+      if (i < nks) ld(i, xa[i], xb[i]);
+      else xa[i] = cd{0.0, 0.0}, xb[i] = cd{0.0, 0.0};
+    }
+    for (int s0 = 0; s0 < nks; s0 += PF) {
+#pragma unroll
+      for (int i = 0; i < PF; ++i) {
+        const cd a = xa[i], b = xb[i];
+        p1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a.x, b.x, p1, 0, 0, 0);
+        p2 = __builtin_amdgcn_mfma_f64_16x16x4f64(a.y, b.y, p2, 0, 0, 0);
+        p3 = __builtin_amdgcn_mfma_f64_16x16x4f64(a.x + a.y, b.x + b.y, p3, 0, 0, 0);
+        if (s0 + PF + i < nks) ld(s0 + PF + i, xa[i], xb[i]);
+        else xa[i] = cd{0.0, 0.0}, xb[i] = cd{0.0, 0.0};
+      }
+    }
+    const v4d_g re = p1 - p2, im = p3 - p1 - p2;
+    if (jb < N) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int i = 16 * tm + q4 + 4 * r;
+        if (i < M) C[(long)i * N + jb] = cd{re[r], im[r]};
+      }
+    }
+  }
+  __syncthreads();
+}
+
 __device__ void wg_copy(cd* __restrict__ dst, const cd* __restrict__ src, const long n) {
   for (long e = threadIdx.x; e < n; e += BT) dst[e] = src[e];
   __syncthreads();
@@ -788,7 +841,7 @@ __device__ __noinline__ void jacobi_precond(cd* A, const long rs, const long cs,
     V[e] = v;
   }
   __syncthreads();
-  wg_gemm<false, false>(S, p, rk, q, A, rs, cs, V, q, 1);  // W[p x rk] (row-major in S) = A V
+  wg_gemm_mfma(S, p, rk, q, A, rs, cs, V, q, 1);  // W[p x rk] (row-major in S) = A V
   for (long e = tid; e < (long)p * q; e += BT) {
     const int i = (int)(e / q), c = (int)(e - (long)i * q);
     A[i * rs + c * cs] = c < rk ? S[(long)i * rk + c] : cd{0.0, 0.0};
@@ -1059,8 +1112,8 @@ __global__ __launch_bounds__(BT, MINWG) void qk_build_kernel(const BuildArgs g) 
           // a large site: t = Q R by Gram-Schmidt twice, u <- R2 (R1 u); the bond keeps its size
           mgs2_qr(t, r, 1, m, r, TMP, LBUF, VV, jl, g.jl_elems);
           if (tid == 0) atomicAdd(g.error + 24, 1);
-          wg_gemm<false, false>(TH, r, 2 * r2, r, LBUF, r, 1, u, 2 * r2, 1);
-          wg_gemm<false, false>(u, r, 2 * r2, r, VV, r, 1, TH, 2 * r2, 1);
+          wg_gemm_mfma(TH, r, 2 * r2, r, LBUF, r, 1, u, 2 * r2, 1);
+          wg_gemm_mfma(u, r, 2 * r2, r, VV, r, 1, TH, 2 * r2, 1);
           for (long e = tid; e < (long)m * r; e += BT) {
             const int row = (int)(e / r), c = (int)(e - (long)row * r);
             t[e] = TMP[(long)c * m + row];
@@ -1104,8 +1157,8 @@ __global__ __launch_bounds__(BT, MINWG) void qk_build_kernel(const BuildArgs g) 
           // a large site: t^T = Q R by Gram-Schmidt twice: t <- Q^T, d <- d R^T = (d R1^T) R2^T ... in the order R = R2 R1: d R^T = (d R1^T) R2^T
           mgs2_qr(t, 1, w, w, l, TMP, LBUF, VV, jl, g.jl_elems);
           if (tid == 0) atomicAdd(g.error + 24, 1);
-          wg_gemm<false, false>(TH, 2 * l0, l, l, d, l, 1, LBUF, 1, l);  // B(a, jj) = R1[jj][a]
-          wg_gemm<false, false>(d, 2 * l0, l, l, TH, l, 1, VV, 1, l);    // B(a, jj) = R2[jj][a]
+          wg_gemm_mfma(TH, 2 * l0, l, l, d, l, 1, LBUF, 1, l);  // B(a, jj) = R1[jj][a]
+          wg_gemm_mfma(d, 2 * l0, l, l, TH, l, 1, VV, 1, l);    // B(a, jj) = R2[jj][a]
           for (long e = tid; e < (long)l * w; e += BT) t[e] = TMP[e];     // t'[jj][i] = Q(i, jj): Q's column jj, contiguous in S
           __syncthreads();
           --centre;
@@ -1140,7 +1193,8 @@ __global__ __launch_bounds__(BT, MINWG) void qk_build_kernel(const BuildArgs g) 
       cd* a1 = sites + (q + 1) * slot;
       const int l = dims[q], mid = dims[q + 1], r = dims[q + 2];
       const int m = 2 * l, nn = 2 * r;
-      wg_gemm<false, false>(TH, m, nn, mid, a0, mid, 1, a1, nn, 1);  // theta[(a,p)][(p',c)]
+      if (mid >= 32) wg_gemm_mfma(TH, m, nn, mid, a0, mid, 1, a1, nn, 1);  // theta[(a,p)][(p',c)]: on the matrix cores from bond 32 on
+      else wg_gemm<false, false>(TH, m, nn, mid, a0, mid, 1, a1, nn, 1);
       {
         const double th = 0.5 * M_PI * alpha[i];
         const double cs = cos(th), sn = sin(th);
