@@ -691,36 +691,57 @@ __device__ void mgs_panels(cd* S, const int p, const int q, const int nbp, const
       }
     }
     __syncthreads();
-    // the trailing columns
-    for (int j = k0 + kn + wave; j < q; j += NWV) {
-      cd* const cj = S + (long)j * p;
-      cd y[RR];
+    // the trailing columns: NC = 2 per wavefront at a time where the registers allow (columns up to 512 rows): one read of a panel
+    // vector serves both and their two reduction chains overlap; the last one of an odd count goes alone
+    constexpr int NC = RR <= 8 ? 2 : 1;
+    for (int j0 = k0 + kn + NC * wave; j0 < q; j0 += NC * NWV) {
+      cd y[NC][RR];
+      bool have[NC];
 #pragma unroll
-      for (int u = 0; u < RR; ++u) {
-        const int i = lane + 64 * u;
-        y[u] = i < p ? cj[i] : cd{0.0, 0.0};
+      for (int c = 0; c < NC; ++c) {
+        have[c] = j0 + c < q;
+        const cd* const cj = S + (long)(have[c] ? j0 + c : j0) * p;
+#pragma unroll
+        for (int u = 0; u < RR; ++u) {
+          const int i = lane + 64 * u;
+          y[c][u] = (have[c] && i < p) ? cj[i] : cd{0.0, 0.0};
+        }
       }
       for (int kk = 0; kk < kn; ++kk) {
-        double dr = 0, di = 0;
+        double dr[NC], di[NC];
+#pragma unroll
+        for (int c = 0; c < NC; ++c) dr[c] = 0, di[c] = 0;
 #pragma unroll
         for (int u = 0; u < RR; ++u) {
           const int i = lane + 64 * u;
           const cd x = i < p ? (cd)QP[kk * p + i] : cd{0.0, 0.0};
-          dr += x.x * y[u].x + x.y * y[u].y, di += x.x * y[u].y - x.y * y[u].x;
+#pragma unroll
+          for (int c = 0; c < NC; ++c) dr[c] += x.x * y[c][u].x + x.y * y[c][u].y, di[c] += x.x * y[c][u].y - x.y * y[c][u].x;
         }
-        dr = wave_sum_f64(dr), di = wave_sum_f64(di);
+#pragma unroll
+        for (int c = 0; c < NC; ++c) dr[c] = wave_sum_f64(dr[c]), di[c] = wave_sum_f64(di[c]);
 #pragma unroll
         for (int u = 0; u < RR; ++u) {
           const int i = lane + 64 * u;
           const cd x = i < p ? (cd)QP[kk * p + i] : cd{0.0, 0.0};
-          y[u] = cd{y[u].x - (dr * x.x - di * x.y), y[u].y - (dr * x.y + di * x.x)};
+#pragma unroll
+          for (int c = 0; c < NC; ++c) y[c][u] = cd{y[c][u].x - (dr[c] * x.x - di[c] * x.y), y[c][u].y - (dr[c] * x.y + di[c] * x.x)};
         }
-        if (lane == 0) put_l(j, k0 + kk, dr, di);
+        if (lane == 0) {
+#pragma unroll
+          for (int c = 0; c < NC; ++c)
+            if (have[c]) put_l(j0 + c, k0 + kk, dr[c], di[c]);
+        }
       }
 #pragma unroll
-      for (int u = 0; u < RR; ++u) {
-        const int i = lane + 64 * u;
-        if (i < p) cj[i] = y[u];
+      for (int c = 0; c < NC; ++c) {
+        if (!have[c]) continue;
+        cd* const cj = S + (long)(j0 + c) * p;
+#pragma unroll
+        for (int u = 0; u < RR; ++u) {
+          const int i = lane + 64 * u;
+          if (i < p) cj[i] = y[c][u];
+        }
       }
     }
     __syncthreads();
