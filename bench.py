@@ -447,6 +447,7 @@ def main():
                 # 3/4 of the K-trimmed part of it (3M complex product): see profiles/r03/<config>/pmc_summary.json
                 "padded_4m_tflop_per_sweep": my["padded_flops"] / 1e12,
                 "work_queues": int(last["queues"]),
+                "edge_sites": int(job.plan.edge_sites),  # sites at either end of the chain taken from per-state edge blocks (contraction order chosen on the host)
                 "launches": launches,
             },
         }

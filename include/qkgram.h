@@ -201,6 +201,15 @@ int64_t qk_plan_first_run(const qk_plan* plan);
  * bookkeeping of G:154, 331-334, 384-385 like the rest of the plan.  Returns the number of queues (16, or 1 for a flat
  * list: then qstart[0] = 0 and qstart[1..16] = num_pairs); qstart may be NULL.                                            */
 int qk_plan_queues(const qk_plan* plan, int64_t* qstart /* [17] */);
+/* EDGE BLOCKS: how many sites at either end of the chain the site-fused sweep takes from per-state blocks instead of walking
+ * them (0: none).  While the bonds still grow like 2^k, contracting the first k sites of each state across their physical legs
+ * into one matrix L[s][a] and starting a pair's environment as X = Ly^T conj(Lx) -- one product with K = 2^k -- is cheaper than k
+ * sites of the chain and saves their per-site costs; likewise at the right end, where the overlap is sum X . (Ry^T conj(Rx)).
+ * The planner picks the k (4..9) that minimises a cost model over a sample of the pairs (qkgram.hip: choose_edge_k; QK_EDGE=0
+ * disables, QK_EDGE=k forces); the blocks are made once per set on first use (2^k x padded bond complex numbers per state and
+ * end; counted by qk_mps_set_info).  This is the host-side choice of the contraction order at the ends of the chain (north star;
+ * reference call site G:380); the algorithmic flop count of qk_stats does not change.                                        */
+int32_t qk_plan_edge_sites(const qk_plan* plan);
 
 /* ---- the hot path -----------------------------------------------------------
  * qk_gram_values: for every pair p of the plan compute z_p = <x_i|y_j> and write

@@ -31,6 +31,16 @@ struct SweepArgs {
   unsigned long long* counter;  // work-queue heads: head of queue s at counter[QK_QSTRIDE * s] (kernels without XCD queues use counter[0] only)
   int nq;                       // queues of this launch: 8 (one per XCD) or 16 (two classes of pairs x 8); <= 1: one list [0, npairs)
   long long qstart[17];         // queue s holds the pairs [qstart[s], qstart[s + 1]) of this launch's list
+  // EDGE BLOCKS (site-fused sweep; edge_k = 0: none): the first and the last edge_k sites of every state contracted into one matrix
+  // each -- left block L[s][a] (s = the 2^edge_k configurations of the first edge_k physical legs, a = bond edge_k), right block
+  // R[s][a] (the last edge_k legs, bond n - edge_k) --, interleaved complex, row-major with the padded bond as leading dimension;
+  // a pair's environment then STARTS as X = Ly^T conj(Lx) (one product with K = 2^edge_k instead of edge_k sites of the chain)
+  // and the overlap ENDS as sum X . (Ry^T conj(Rx)).  xedge_offs / yedge_offs: [n_states][2] element offsets of (L, R).
+  const double* xedge;
+  const long long* xedge_offs;
+  const double* yedge;
+  const long long* yedge_offs;
+  int edge_k;
   unsigned long long* tail;     // per-launch device clocks (s_memrealtime, 100 MHz): [0] first workgroup start, [1] first workgroup exit, [4] last workgroup exit
   unsigned long long* prof;  // diagnostic build only: cycle sums per section (see QK_VARIANT=9)
   int debug_flags;           // timing experiments only (QK_DEBUG_FLAGS): bit 0 = skip epilogue stores, bit 1 = skip steady-state fetch/stash, bit 2 = skip MFMAs, bit 3 = skip steady-state barriers (all give WRONG results)

@@ -184,6 +184,74 @@ __device__ __forceinline__ void qkf_rotate(QkfTile (&T)[S], const int L) {  // t
   }
 }
 
+// ----------------------------------------------------------------------------------------
+// Edge blocks (SweepArgs.edge_k): the contraction order chosen on the host for the ENDS of the chain.  While the bonds still grow
+// like 2^k, contracting the first k sites of each state into one matrix L[s][a] and taking X = Ly^T conj(Lx) -- one product with
+// K = 2^k -- is cheaper than k sites of the chain, and it saves their per-site costs (two barriers, set-up, load latencies: 3-5 us
+// each, as much as the matrix work of a 64 x 64 site); likewise at the right end, where the overlap is sum_{b,a} X[b][a] R[b][a]
+// with R = Ry^T conj(Rx).  On the 60-qubit x 6-layer set the model picks k = 8: 16 of 60 sites go.
+// ----------------------------------------------------------------------------------------
+// One 16 x 16 tile of  Ay^T conj(Ax)  (K = ks4 k-steps of 4 rows): Ay / Ax point at this lane's element of k-step 0 (row q, column
+// 16 t + j), ldy / ldx = elements per row.
+__device__ __forceinline__ void qkf_edge_tile(QkfTile& t, const v2d* __restrict__ Ay, const int ldy, const v2d* __restrict__ Ax, const int ldx, const int ks4) {
+  v4d p1 = {0, 0, 0, 0}, p2 = {0, 0, 0, 0}, p3 = {0, 0, 0, 0};
+  v2d fy[4], fx[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) fy[i] = Ay[(long)(4 * i) * ldy], fx[i] = Ax[(long)(4 * i) * ldx];  // (ks4 >= 4: K = 2^k >= 16)
+  for (int s0 = 0; s0 < ks4; s0 += 4) {
+    const bool more = s0 + 4 < ks4;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      qkf_kstep<true>(p1, p2, p3, fy[i].x, fy[i].y, fx[i].x, fx[i].y);
+      if (more) fy[i] = Ay[(long)(4 * (s0 + 4 + i)) * ldy], fx[i] = Ax[(long)(4 * (s0 + 4 + i)) * ldx];
+    }
+  }
+  t.re = p1 + p2, t.im = p3 - p1 + p2;
+}
+
+// The environment behind the left edge: X[b][a] = sum_s Ly[s][b] conj(Lx[s][a]), b x a (padded bonds of site edge_k), written
+// row-major with stride a to `xo` (LDS or the global X buffer); tiles dealt round-robin to the NW wavefronts.
+template <int NW, typename XOut>
+__device__ __forceinline__ void qkf_edge_prefix(const SweepArgs& g, const int xi, const int yj, const int a, const int b, XOut xo, const int wave, const int q, const int j) {
+  const v2d* const Lx = reinterpret_cast<const v2d*>(g.xedge) + g.xedge_offs[2 * (long long)xi];
+  const v2d* const Ly = reinterpret_cast<const v2d*>(g.yedge) + g.yedge_offs[2 * (long long)yj];
+  const int mt = a / TILE, nt = b / TILE, ks4 = (1 << g.edge_k) >> 2;
+  for (int t = wave; t < mt * nt; t += NW) {
+    const int tb = t / mt, ta = t - tb * mt;
+    QkfTile T;
+    qkf_edge_tile(T, Ly + (long)q * b + tb * TILE + j, b, Lx + (long)q * a + ta * TILE + j, a, ks4);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) xo[(tb * TILE + q + 4 * r) * a + ta * TILE + j] = (v2d){T.re[r], T.im[r]};
+  }
+}
+
+// The overlap at the right edge: z = sum_{b,a} X[b][a] R[b][a], R = Ry^T conj(Rx); X row-major with stride a at `xin`.  Every
+// wavefront adds its tiles' share to the two doubles at `zacc` (LDS, zeroed by the caller behind a barrier).
+template <int NW, typename XIn>
+__device__ __forceinline__ void qkf_edge_suffix(const SweepArgs& g, const int xi, const int yj, const int a, const int b, XIn xin, __attribute__((address_space(3))) double* zacc, const int wave,
+                                                const int q, const int j) {
+  const v2d* const Rx = reinterpret_cast<const v2d*>(g.xedge) + g.xedge_offs[2 * (long long)xi + 1];
+  const v2d* const Ry = reinterpret_cast<const v2d*>(g.yedge) + g.yedge_offs[2 * (long long)yj + 1];
+  const int mt = a / TILE, nt = b / TILE, ks4 = (1 << g.edge_k) >> 2;
+  double zr = 0, zi = 0;
+  for (int t = wave; t < mt * nt; t += NW) {
+    const int tb = t / mt, ta = t - tb * mt;
+    QkfTile T;
+    qkf_edge_tile(T, Ry + (long)q * b + tb * TILE + j, b, Rx + (long)q * a + ta * TILE + j, a, ks4);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const v2d x = xin[(tb * TILE + q + 4 * r) * a + ta * TILE + j];
+      zr += x.x * T.re[r] - x.y * T.im[r], zi += x.x * T.im[r] + x.y * T.re[r];
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) zr += __shfl_xor(zr, o), zi += __shfl_xor(zi, o);
+  if ((q | j) == 0 && wave < mt * nt) {
+    __hip_atomic_fetch_add(zacc, zr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    __hip_atomic_fetch_add(zacc + 1, zi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  }
+}
+
 // What a site needs: bonds, tile counts, where its X / X' live and how its items are cut into strips.
 struct QkfSite {
   int a, a2, b, b2, at, nks, mt, nt, nn, W, inv;  // inv = ceil(2^20 / mt): u / mt == (u * inv) >> 20 for u < 2048, mt <= 32 (checked exhaustively)
@@ -209,8 +277,9 @@ __global__ __launch_bounds__(64 * NW, WPS) void qk_sweep_fused_kernel(const Swee
   // per-site records of the current pair, built by all threads at pair set-up: 12 ints (48 bytes) per site
   //   [0] a  [1] a2  [2] b  [3] b2  [4] true a  [5] k-steps of b  [6] W  [7] small  [8] ceil(2^20 / mt)  [9] -  [10..11] -
   // and the two tensor offsets (elements of the interleaved image) as int64 in a second table
-  lds_v4i* const rec = (lds_v4i*)(slot + 2);
-  long long* const m_off = reinterpret_cast<long long*>(slot + 2) + 6 * (long long)ns;  // [ns][2]: A_k, B_k
+  __attribute__((address_space(3))) double* const zacc = (__attribute__((address_space(3))) double*)(slot + 2);  // the overlap's two doubles (edge blocks)
+  lds_v4i* const rec = (lds_v4i*)(slot + 4);
+  long long* const m_off = reinterpret_cast<long long*>(slot + 4) + 6 * (long long)ns;  // [ns][2]: A_k, B_k
   auto rfl = [&](const int v) __attribute__((always_inline)) { return __builtin_amdgcn_readfirstlane(v); };
   auto ldl = [&](const long long* p_) __attribute__((always_inline)) {
     const long long v = *p_;
@@ -274,18 +343,28 @@ __global__ __launch_bounds__(64 * NW, WPS) void qk_sweep_fused_kernel(const Swee
       m_off[2 * e] = g.xoffs[(long long)xi * ns + e] >> 1;
       m_off[2 * e + 1] = g.yoffs[(long long)yj * ns + e] >> 1;
     }
-    for (int e = tid; e < TILE * TILE; e += NT) XL[e] = (v2d){e == 0 ? 1.0 : 0.0, 0.0};  // X_0 = 1 in a 16 x 16 block
+    const int ek = g.edge_k, k_hi = ns - ek;  // the chain runs over the sites [ek, k_hi): the ends are in the edge blocks
+    if (ek == 0)
+      for (int e = tid; e < TILE * TILE; e += NT) XL[e] = (v2d){e == 0 ? 1.0 : 0.0, 0.0};  // X_0 = 1 in a 16 x 16 block
+    if (tid == 0) zacc[0] = 0.0, zacc[1] = 0.0;
     __syncthreads();
-    QKF_STAMP(0);  // pair set-up
     bool xg = false;  // where X lives: LDS (at element xb, row stride a) or the global buffer G0 + cur * x_plane
     int cur = 0, xb = 0;
+    if (ek > 0) {  // X behind the left edge: one product of the two left blocks
+      const v4i r0 = rec[3 * ek];
+      const int a_e = rfl(r0.x), b_e = rfl(r0.z);
+      if (a_e * b_e <= XCAP) qkf_edge_prefix<NW>(g, xi, yj, a_e, b_e, XL, wave, q, j);
+      else qkf_edge_prefix<NW>(g, xi, yj, a_e, b_e, G0, wave, q, j), xg = true;
+      __syncthreads();
+    }
+    QKF_STAMP(0);  // pair set-up
     QkfTile T[S];
     v2d fr[4];            // the fragment registers of the wave's global stream: they carry its next group across tiles and barriers
     bool primed = false;  // fr holds the first group of the wave's next tile
-    QkfSite sn = site(0);
-    for (int k = 0; k < ns; ++k) {
+    QkfSite sn = site(ek);
+    for (int k = ek; k < k_hi; ++k) {
       const QkfSite sc = sn;
-      if (k + 1 < ns) sn = site(k + 1);
+      if (k + 1 < k_hi) sn = site(k + 1);
       const int a = sc.a, a2 = sc.a2, b = sc.b, mt = sc.mt, nt = sc.nt, W = sc.W;
       const bool small = sc.small;
       v2d* const Gc = G0 + (long long)cur * g.x_plane;
@@ -357,7 +436,7 @@ __global__ __launch_bounds__(64 * NW, WPS) void qk_sweep_fused_kernel(const Swee
             const int kmax = min(4, (sc.at - ta * TILE + 3) >> 2);
             const bool more = s + 1 < S && it + NW < items;
             // after the wave's last item of the site: its first tile of the next site (strip 0, round 0), if it has one
-            const bool chain = !more && last_round && k + 1 < ns && wave < 2 * sn.mt * min(sn.W, sn.nt);
+            const bool chain = !more && last_round && k + 1 < k_hi && wave < 2 * sn.mt * min(sn.W, sn.nt);
             const QkfStream nxt = more ? a_stream(sc, it + NW) : chain ? b_stream(sn, 0, wave) : a_stream(sc, it);
             if (kmax == 4) qkf_p2_item<true>(T[S - 1], fr, primed, a_stream(sc, it), a2, sc.nn, 4, XL + ob + tbl * TILE * a2, q, j, nxt);
             else qkf_p2_item<false>(T[S - 1], fr, primed, a_stream(sc, it), a2, sc.nn, kmax, XL + ob + tbl * TILE * a2, q, j, nxt);
@@ -380,8 +459,15 @@ __global__ __launch_bounds__(64 * NW, WPS) void qk_sweep_fused_kernel(const Swee
         xb = ob;
       }
     }
+    if (ek > 0) {  // the overlap: X against the product of the two right blocks
+      const v4i r0 = rec[3 * (k_hi - 1)];
+      const int a_e = rfl(r0.y), b_e = rfl(r0.w);
+      if (xg) qkf_edge_suffix<NW>(g, xi, yj, a_e, b_e, (const v2d*)(G0 + (long long)cur * g.x_plane), zacc, wave, q, j);
+      else qkf_edge_suffix<NW>(g, xi, yj, a_e, b_e, (const lds_v2d*)(XL + xb), zacc, wave, q, j);
+      __syncthreads();
+    }
     if (tid == 0) {
-      const v2d zz = xg ? G0[(long long)cur * g.x_plane] : (v2d)XL[xb];
+      const v2d zz = ek > 0 ? (v2d){zacc[0], zacc[1]} : xg ? G0[(long long)cur * g.x_plane] : (v2d)XL[xb];
       g.values[p] = zz.x * zz.x + zz.y * zz.y;
       if (g.z) {
         g.z[2 * p] = zz.x;
@@ -504,8 +590,9 @@ __global__ __launch_bounds__(64 * NW, WPS) void qk_sweep_fused_dual_kernel(const
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int j = lane & 15, q = lane >> 4;
   const int ns = g.n_sites, n1 = ns + 1;
-  lds_v4i* const rec = (lds_v4i*)(slot + 2);  // per-site records as in qk_sweep_fused_kernel
-  long long* const m_off = reinterpret_cast<long long*>(slot + 2) + 6 * (long long)ns;
+  __attribute__((address_space(3))) double* const zacc = (__attribute__((address_space(3))) double*)(slot + 2);
+  lds_v4i* const rec = (lds_v4i*)(slot + 4);  // per-site records as in qk_sweep_fused_kernel
+  long long* const m_off = reinterpret_cast<long long*>(slot + 4) + 6 * (long long)ns;
   auto rfl = [&](const int v) __attribute__((always_inline)) { return __builtin_amdgcn_readfirstlane(v); };
   auto ldl = [&](const long long* p_) __attribute__((always_inline)) {
     const long long v = *p_;
@@ -576,17 +663,27 @@ __global__ __launch_bounds__(64 * NW, WPS) void qk_sweep_fused_dual_kernel(const
       m_off[2 * e] = g.xoffs[(long long)xi * ns + e] >> 1;
       m_off[2 * e + 1] = g.yoffs[(long long)yj * ns + e] >> 1;
     }
-    for (int e = tid; e < TILE * TILE; e += NT) XL[e] = (v2d){e == 0 ? 1.0 : 0.0, 0.0};
+    const int ek = g.edge_k, k_hi = ns - ek;  // the chain runs over the sites [ek, k_hi): the ends are in the edge blocks
+    if (ek == 0)
+      for (int e = tid; e < TILE * TILE; e += NT) XL[e] = (v2d){e == 0 ? 1.0 : 0.0, 0.0};
+    if (tid == 0) zacc[0] = 0.0, zacc[1] = 0.0;
     __syncthreads();
     bool xg = false;
     int cur = 0, xb = 0;
+    if (ek > 0) {  // X behind the left edge: one product of the two left blocks
+      const v4i r0 = rec[3 * ek];
+      const int a_e = rfl(r0.x), b_e = rfl(r0.z);
+      if (a_e * b_e <= XCAP) qkf_edge_prefix<NW>(g, xi, yj, a_e, b_e, XL, wave, q, j);
+      else qkf_edge_prefix<NW>(g, xi, yj, a_e, b_e, G0, wave, q, j), xg = true;
+      __syncthreads();
+    }
     QkfTile T0, T1;
     v2d fr[4], fs[4];     // the fragment registers of the wave's global streams (fs: the second column block of phase 1)
     bool primed = false;  // fr / fs hold the first group of the wave's next pair of tiles
-    QkfSite sn = site(0);
-    for (int k = 0; k < ns; ++k) {
+    QkfSite sn = site(ek);
+    for (int k = ek; k < k_hi; ++k) {
       const QkfSite sc = sn;
-      if (k + 1 < ns) sn = site(k + 1);
+      if (k + 1 < k_hi) sn = site(k + 1);
       const int a = sc.a, a2 = sc.a2, b = sc.b, mt = sc.mt, nt = sc.nt, W = sc.W;
       const bool small = sc.small;
       v2d* const Gc = G0 + (long long)cur * g.x_plane;
@@ -647,7 +744,7 @@ __global__ __launch_bounds__(64 * NW, WPS) void qk_sweep_fused_dual_kernel(const
               const int w2 = min(W, nt - s0 - W);
               const Unit nu = unit_of(sc, w2, 2 * mt * ((w2 + 1) >> 1), 0);
               if (nu.mine) nxt = b_stream(sc, s0 + W, nu.v, nu.half), np1 = true;
-            } else if (k + 1 < ns) {
+            } else if (k + 1 < k_hi) {
               const int w2 = min(sn.W, sn.nt);
               const Unit nu = unit_of(sn, w2, 2 * sn.mt * ((w2 + 1) >> 1), 0);
               if (nu.mine) nxt = b_stream(sn, 0, nu.v, nu.half), np1 = true;
@@ -677,8 +774,15 @@ __global__ __launch_bounds__(64 * NW, WPS) void qk_sweep_fused_dual_kernel(const
         xb = ob;
       }
     }
+    if (ek > 0) {  // the overlap: X against the product of the two right blocks
+      const v4i r0 = rec[3 * (k_hi - 1)];
+      const int a_e = rfl(r0.y), b_e = rfl(r0.w);
+      if (xg) qkf_edge_suffix<NW>(g, xi, yj, a_e, b_e, (const v2d*)(G0 + (long long)cur * g.x_plane), zacc, wave, q, j);
+      else qkf_edge_suffix<NW>(g, xi, yj, a_e, b_e, (const lds_v2d*)(XL + xb), zacc, wave, q, j);
+      __syncthreads();
+    }
     if (tid == 0) {
-      const v2d zz = xg ? G0[(long long)cur * g.x_plane] : (v2d)XL[xb];
+      const v2d zz = ek > 0 ? (v2d){zacc[0], zacc[1]} : xg ? G0[(long long)cur * g.x_plane] : (v2d)XL[xb];
       g.values[p] = zz.x * zz.x + zz.y * zz.y;
       if (g.z) {
         g.z[2 * p] = zz.x;

@@ -67,6 +67,11 @@ struct qk_mps_set {
   int64_t* d_offs = nullptr;  // re-plane offsets (doubles) [n_states][n_sites]
   std::vector<int32_t> dims_true;
   int64_t bytes = 0;
+  // edge blocks of the site-fused sweep (made on first use for the plan's edge_k; qk_device.h: SweepArgs.edge_k)
+  double* d_edge = nullptr;        // interleaved complex: per state the left block [2^k][pad(chi_k)], then the right block [2^k][pad(chi_{n-k})]
+  long long* d_edge_offs = nullptr;  // [n_states][2] element offsets
+  int edge_k = 0;
+  int64_t edge_bytes = 0;
 };
 
 struct qk_plan {
@@ -83,6 +88,7 @@ struct qk_plan {
   int64_t n_first = 0;     // pairs [n_first, end) are the class whose sites fit the fused sweep's smaller LDS buffer (== number of pairs: no split)
   int nq = 1;                 // device work queues: 1 = one list; 16 = two classes of pairs x 8 XCD queues (the second class may be empty)
   int64_t qstart[17] = {0};   // queue s = pairs [qstart[s], qstart[s + 1]) of this rank's list; queues 8..15 = the class-1 run
+  int edge_k = 0;             // sites at either end of the chain that the fused sweep takes from the sets' edge blocks (0: none)
   bool second_wave2 = false;  // the second run holds the pairs of two states whose bonds are all <= 32: swept by the one-wave kernel (mixed sets)
   double fit_two = 1.0;  // share of this rank's padded work in sites whose X and X' fit the fused sweep's smaller LDS buffer
   // lazily uploaded copy

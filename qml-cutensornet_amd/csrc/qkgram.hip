@@ -198,6 +198,51 @@ static double fused_cost(int n, const int32_t* a, const int32_t* b) {
   return c;
 }
 
+// How many sites at either end of the chain the site-fused sweep should take from edge blocks (qk_fused.h: qkf_edge_prefix /
+// qkf_edge_suffix) instead of walking them: the k that minimises, over a sample of this rank's pairs, the matrix instructions of
+// the sweep plus a fixed cost per site walked (two barriers, set-up, load latencies: 375 instructions' worth = 2.5 us of a 12-wave
+// workgroup, measured on uniform small chains, tools/site_overhead.py).  A block product costs tiles(a_k) tiles(b_k) 2^k / 4 x 3
+// instructions x 1.5 (its tiles stream both blocks from L2: calibrated on the 60-qubit x 6-layer set, where k = 5 / 6 / 7 / 8 / 9
+// measured 98.3 / 97.6 / 96.2 / 95.5 / 98.0 % of the plain sweep); the chain's cost is fused_cost's.  QK_EDGE=0 disables, QK_EDGE=k forces.  This is a contraction order chosen on the
+// host (north star; reference call site G:380): while the bonds still grow like 2^k, the ends of the two states are cheaper to
+// contract across their physical legs than along the chain.
+static int choose_edge_k(const int n_sites, const int32_t* x_dims, const int32_t* y_dims, const std::vector<int32_t>& pairs) {
+  constexpr int KMIN = 4, KMAX = 9;  // K = 2^k >= 16 (four k-steps in flight); 2^9 rows per block at most
+  if (const char* e = std::getenv("QK_EDGE")) {
+    const int v = std::atoi(e);
+    if (v <= 0) return 0;
+    return (v >= KMIN && v <= KMAX && n_sites >= 2 * v + 2) ? v : 0;
+  }
+  const int64_t np = (int64_t)pairs.size() / 2;
+  if (np == 0 || n_sites < 2 * KMIN + 2) return 0;
+  const int stride = n_sites + 1;
+  const int64_t step = std::max<int64_t>(1, np / 512);
+  const double over = 375.0;
+  auto t16 = [](const int v) { return (double)((v + 15) / 16); };
+  std::vector<double> total((size_t)KMAX + 1, 0.0);
+  for (int64_t t = 0; t < np; t += step) {
+    const int32_t* a = x_dims + (int64_t)pairs[2 * t] * stride;
+    const int32_t* b = y_dims + (int64_t)pairs[2 * t + 1] * stride;
+    std::vector<double> site((size_t)n_sites);
+    for (int k = 0; k < n_sites; ++k)
+      site[(size_t)k] = 6 * t16(a[k]) * t16(b[k + 1]) * ((b[k] + 3) / 4) + 6 * t16(b[k + 1]) * t16(a[k + 1]) * ((a[k] + 3) / 4) + over;
+    double chain = 0;
+    for (double v : site) chain += v;
+    total[0] += chain;
+    double ends = 0;  // cost of the sites the edges replace
+    for (int k = 1; k <= KMAX && n_sites >= 2 * k + 2; ++k) {
+      ends += site[(size_t)k - 1] + site[(size_t)(n_sites - k)];
+      if (k < KMIN) continue;
+      const double blocks = 1.5 * 3.0 * ((1 << k) / 4) * (t16(a[k]) * t16(b[k]) + t16(a[n_sites - k]) * t16(b[n_sites - k])) + 2 * over;
+      total[(size_t)k] += chain - ends + blocks;
+    }
+  }
+  int best = 0;
+  for (int k = KMIN; k <= KMAX && n_sites >= 2 * k + 2; ++k)
+    if (total[(size_t)k] > 0 && total[(size_t)k] < total[(size_t)best] * 0.995) best = k;
+  return best;
+}
+
 // ----------------------------------------------------------------------------------------
 // The tiled plan: XCD-aware work queues (default; QK_PLAN_XCD=0 or an explicit locality `block` selects the flat list).
 // An MI355X has 8 XCDs with a private 4 MiB L2 each, and blocks are dealt to them round-robin.  With one cost-ordered list
@@ -366,6 +411,7 @@ static void plan_tiled(qk_plan* p, const int n_sites, const int nx, const int32_
   p->stats.pairs = np;
   p->stats.flops = flops, p->stats.padded_flops = padded, p->stats.bytes = bytes;
   p->fit_two = padded > 0 ? fit_two / padded : 1.0;
+  p->edge_k = choose_edge_k(n_sites, x_dims, y_dims, p->pairs);
 }
 
 extern "C" int qk_plan_create(int32_t n_sites, int32_t nx, const int32_t* x_dims, int32_t ny, const int32_t* y_dims,
@@ -567,6 +613,7 @@ extern "C" int qk_plan_create(int32_t n_sites, int32_t nx, const int32_t* x_dims
   p->stats.flops = flops, p->stats.padded_flops = padded, p->stats.bytes = bytes;
   p->fit_two = padded > 0 ? fit_two / padded : 1.0;
   p->nq = 1;  // the flat list: one queue per launch
+  p->edge_k = choose_edge_k(n_sites, x_dims, y_dims, p->pairs);
   *out = p;
   return QK_OK;
 }
@@ -583,6 +630,7 @@ extern "C" int64_t qk_plan_total_pairs(const qk_plan* p) { return p ? p->total_p
 extern "C" int64_t qk_plan_max_pairs_per_rank(const qk_plan* p) { return p ? p->max_per_rank : 0; }
 extern "C" const int32_t* qk_plan_pairs(const qk_plan* p) { return p ? p->pairs.data() : nullptr; }
 extern "C" int64_t qk_plan_first_run(const qk_plan* p) { return p ? (p->n_first > 0 ? p->n_first : (int64_t)p->pairs.size() / 2) : 0; }
+extern "C" int32_t qk_plan_edge_sites(const qk_plan* p) { return p ? p->edge_k : 0; }
 extern "C" int qk_plan_queues(const qk_plan* p, int64_t* qstart) {
   if (!p) return 0;
   if (qstart)
@@ -611,6 +659,51 @@ __global__ void qk_scatter_kernel(const int32_t* __restrict__ pairs, const doubl
   const double v = vals[t];
   K[(long long)j * ld + i] = v;
   if (mirror) K[(long long)i * ld + j] = v;
+}
+
+// Edge blocks of a set (SweepArgs.edge_k; qk_fused.h): per state the first k sites contracted into L[s][a] (s = the configuration of
+// the first k physical legs, row index built as 2 s + p site by site; a = bond k, padded) and the last k sites into R[s][a] (a = bond
+// n - k).  One workgroup per (state, side) at a time; a step multiplies the block so far by one site tensor (split planes of the
+// set image), ping-pong between two scratch buffers of the workgroup, the last step writes the destination.  Interleaved complex.
+typedef double qk_v2d __attribute__((ext_vector_type(2)));
+__global__ __launch_bounds__(256) void qk_edge_kernel(const double* __restrict__ data, const int32_t* __restrict__ dims, const int64_t* __restrict__ offs, const int n_sites, const int k,
+                                                      const long long n_states, qk_v2d* __restrict__ edge, const long long* __restrict__ edge_offs, qk_v2d* __restrict__ tmp,
+                                                      const long long tmp_elems) {
+  qk_v2d* const t0 = tmp + (long long)blockIdx.x * 2 * tmp_elems;
+  qk_v2d* const t1 = t0 + tmp_elems;
+  const int n1 = n_sites + 1;
+  for (long long t = blockIdx.x; t < 2 * n_states; t += gridDim.x) {
+    const long long st = t >> 1;
+    const int right = (int)(t & 1);
+    const int32_t* d = dims + st * n1;
+    qk_v2d* const dst = edge + edge_offs[t];
+    // the block before the first step: one row, 1 at [0][0] (the boundary bond is 1, padded to 16)
+    for (int e = threadIdx.x; e < 16; e += blockDim.x) t0[e] = (qk_v2d){e == 0 ? 1.0 : 0.0, 0.0};
+    __syncthreads();
+    const qk_v2d* in = t0;
+    for (int jj = 0; jj < k; ++jj) {
+      const int site = right ? n_sites - 1 - jj : jj;
+      const int lp = d[site], rp = d[site + 1];  // padded bonds of the site tensor [lp][2][rp]
+      const double* re = data + offs[st * n_sites + site];
+      const double* im = re + (long long)lp * 2 * rp;
+      const int ld_in = right ? rp : lp, ld_out = right ? lp : rp, rows_in = 1 << jj;
+      qk_v2d* const out = (jj + 1 == k) ? dst : (in == t0 ? t1 : t0);
+      for (int e = threadIdx.x; e < 2 * rows_in * ld_out; e += blockDim.x) {
+        const int row = e / ld_out, c = e - row * ld_out, s_ = row >> 1, pp = row & 1;
+        double ar = 0, ai = 0;
+        for (int l = 0; l < ld_in; ++l) {
+          const qk_v2d x = in[(long long)s_ * ld_in + l];
+          // left: A[l][pp][c];  right: A[c][pp][l]
+          const long long idx = right ? ((long long)(c * 2 + pp) * rp + l) : ((long long)(l * 2 + pp) * rp + c);
+          const double tr = re[idx], ti = im[idx];
+          ar += x.x * tr - x.y * ti, ai += x.x * ti + x.y * tr;
+        }
+        out[e] = (qk_v2d){ar, ai};
+      }
+      __syncthreads();
+      in = out;
+    }
+  }
 }
 
 // self-test: C[16x16] = sum_{k<16} P[k][m] * Q[k][n] with the fragment maps used above
@@ -824,6 +917,8 @@ extern "C" int qk_mps_set_destroy(qk_mps_set* m) {
   (void)hipStreamSynchronize(m->ctx->stream);
   if (m->d_data) (void)hipFree(m->d_data);
   if (m->d_il) (void)hipFree(m->d_il);
+  if (m->d_edge) (void)hipFree(m->d_edge);
+  if (m->d_edge_offs) (void)hipFree(m->d_edge_offs);
   if (m->d_dims) (void)hipFree(m->d_dims);
   if (m->d_true) (void)hipFree(m->d_true);
   if (m->d_offs) (void)hipFree(m->d_offs);
@@ -836,7 +931,7 @@ extern "C" int qk_mps_set_info(const qk_mps_set* m, int32_t* n_states, int32_t* 
   if (n_states) *n_states = m->n_states;
   if (n_sites) *n_sites = m->n_sites;
   if (max_padded_bond) *max_padded_bond = m->max_pad;
-  if (device_bytes) *device_bytes = m->bytes * (m->d_il ? 2 : 1);  // the interleaved twin the fused / wave2 sweeps make on first use counts
+  if (device_bytes) *device_bytes = m->bytes * (m->d_il ? 2 : 1) + m->edge_bytes;  // the interleaved twin the fused / wave2 sweeps make on first use counts
   return QK_OK;
 }
 
@@ -957,6 +1052,40 @@ static int ensure_interleaved(qk_ctx* c, qk_mps_set* m) {
   return QK_OK;
 }
 
+// the edge blocks of a set for `k` sites at either end (made once per set and k; fp64 sets)
+static int ensure_edges(qk_ctx* c, qk_mps_set* m, const int k) {
+  if (k <= 0 || (m->d_edge && m->edge_k == k)) return QK_OK;
+  if (m->d_edge) (void)hipFree(m->d_edge);
+  if (m->d_edge_offs) (void)hipFree(m->d_edge_offs);
+  m->d_edge = nullptr, m->d_edge_offs = nullptr, m->edge_k = 0, m->edge_bytes = 0;
+  const int n = m->n_sites, stride = n + 1;
+  std::vector<long long> offs((size_t)m->n_states * 2);
+  long long total = 0;
+  int maxld = 16;
+  for (int s_ = 0; s_ < m->n_states; ++s_) {
+    const int32_t* d = m->dims_true.data() + (size_t)s_ * stride;
+    offs[(size_t)2 * s_] = total;
+    total += (long long)(1 << k) * pad16(d[k]);
+    offs[(size_t)2 * s_ + 1] = total;
+    total += (long long)(1 << k) * pad16(d[n - k]);
+    for (int jj = 0; jj <= k; ++jj) maxld = std::max(maxld, std::max(pad16(d[jj]), pad16(d[n - jj])));
+  }
+  const long long tmp_elems = (long long)(1 << (k - 1)) * maxld;  // the largest intermediate block
+  const int grid = (int)std::min<long long>(2ll * m->n_states, 4ll * c->num_cus);
+  DevBuf eb, ob, tb;
+  HIP_TRY(eb.alloc((size_t)total * 2 * sizeof(double)));
+  HIP_TRY(ob.alloc(offs.size() * sizeof(long long)));
+  HIP_TRY(tb.alloc((size_t)grid * 2 * tmp_elems * 2 * sizeof(double)));
+  HIP_TRY(hipMemcpyAsync(ob.p, offs.data(), offs.size() * sizeof(long long), hipMemcpyHostToDevice, c->stream));
+  qk_edge_kernel<<<dim3(grid), dim3(256), 0, c->stream>>>(m->d_data, m->d_dims, m->d_offs, n, k, m->n_states, eb.as<qk_v2d>(), ob.as<long long>(), tb.as<qk_v2d>(), tmp_elems);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipStreamSynchronize(c->stream));  // (the scratch goes out of scope; once per set)
+  m->d_edge = eb.as<double>(), m->d_edge_offs = ob.as<long long>();
+  eb.p = nullptr, ob.p = nullptr;
+  m->edge_k = k, m->edge_bytes = total * 2 * (long long)sizeof(double);
+  return QK_OK;
+}
+
 static int ensure_plan_uploaded(qk_ctx* c, qk_plan* p) {
   if (p->d_pairs && p->up_ctx == c) return QK_OK;
   if (p->d_pairs) {
@@ -1015,7 +1144,7 @@ extern "C" int qk_gram_values(qk_ctx* c, const qk_mps_set* xs, const qk_mps_set*
   // X: on the 60-qubit x 6-layer headline set (57 % of the work fits) the two shapes are within 2 % in time while the
   // smaller buffer moves 3.2 instead of 1.9 TB through the fabric -- so two workgroups only when >= 75 % of the padded
   // work fits.  A 16-row strip of X' must fit the buffer: bonds <= XCAP / 16.
-  const size_t lds_meta = 16 + (size_t)xs->n_sites * (48 + 16);  // queue slot, per-site records and tensor offsets
+  const size_t lds_meta = 32 + (size_t)xs->n_sites * (48 + 16);  // queue slot, the overlap's accumulator, per-site records and tensor offsets
   const bool fused_ok = c->variant == 20 && !f32 && !quad && c->fused_path != 0 && max_pad > (c->fused_path >= 2 ? 16 : 32);
   const bool can_one = max_pad <= QKF_XCAP_ONE / TILE && (size_t)QKF_XCAP_ONE * 16 + lds_meta <= 160 * 1024;
   const bool can_two = max_pad <= QKF_XCAP_TWO / TILE && (size_t)QKF_XCAP_TWO * 16 + lds_meta <= 80 * 1024;
@@ -1047,6 +1176,7 @@ extern "C" int qk_gram_values(qk_ctx* c, const qk_mps_set* xs, const qk_mps_set*
   a.groups = plan->d_groups, a.ngroups = (long long)plan->groups.size() / 2;
   a.values = values_dev, a.z = z_dev;
   a.scratch = c->scratch, a.x_plane = x_plane, a.t_plane = t_plane;
+  a.xedge = a.yedge = nullptr, a.xedge_offs = a.yedge_offs = nullptr, a.edge_k = 0;
   a.counter = c->counter;
   a.nq = 1;  // kernels with XCD queues (site-fused, wave2) get the plan's queues below
   for (int s_ = 0; s_ <= QK_NQ_MAX; ++s_) a.qstart[s_] = plan->nq > 1 ? plan->qstart[s_] : (s_ == 0 ? 0 : np);
@@ -1110,6 +1240,13 @@ extern "C" int qk_gram_values(qk_ctx* c, const qk_mps_set* xs, const qk_mps_set*
       if (rc_il != QK_OK) return rc_il;
     }
     a.xdata = xs->d_il, a.ydata = ys->d_il;
+    if (plan->edge_k > 0) {  // the ends of the chain from the sets' edge blocks (chosen by the planner)
+      for (const qk_mps_set* m : {xs, ys}) {
+        const int rc_e = ensure_edges(c, const_cast<qk_mps_set*>(m), plan->edge_k);
+        if (rc_e != QK_OK) return rc_e;
+      }
+      a.xedge = xs->d_edge, a.xedge_offs = xs->d_edge_offs, a.yedge = ys->d_edge, a.yedge_offs = ys->d_edge_offs, a.edge_k = plan->edge_k;
+    }
     a.x_plane = (long long)xs->max_pad * ys->max_pad;  // complex elements per global X buffer (two per workgroup)
     HIP_TRY(hipEventRecord(c->ev0, c->stream));        // the conversion above is not part of the sweep
     a.nq = plan->nq, c->last.queues = plan->nq > 1 ? 8 : 1, c->tail_pending = true;

@@ -83,6 +83,7 @@ _SIGNATURES = [
     ("qk_plan_stats", C.c_int, [_P, C.POINTER(QkStats)]),
     ("qk_plan_first_run", C.c_int64, [_P]),
     ("qk_plan_queues", C.c_int, [_P, _P]),
+    ("qk_plan_edge_sites", C.c_int32, [_P]),
     ("qk_gram_values", C.c_int, [_P, _P, _P, _P, _P, _P]),
     ("qk_gram_values_host", C.c_int, [_P, _P, _P, _P, _P, _P]),
     ("qk_scatter", C.c_int, [_P, _P, _P, C.c_int64, _P, C.c_int64, C.c_int32]),
@@ -257,6 +258,11 @@ class Plan:
     def first_run(self) -> int:
         """Pairs [first_run, num_pairs) are the run the site-fused sweep takes with its two-workgroups-per-CU shape."""
         return int(lib().qk_plan_first_run(self._h))
+
+    @property
+    def edge_sites(self) -> int:
+        """Sites at either end of the chain that the site-fused sweep takes from the sets' edge blocks (0: none)."""
+        return int(lib().qk_plan_edge_sites(self._h))
 
     def queues(self):
         """(number of device work queues, qstart[17]): queue s = pairs [qstart[s], qstart[s+1]) -- 8 per run of the list, one

@@ -775,3 +775,33 @@ def test_mixed_set_keeps_small_pairs_on_the_one_wave_sweep(gpu_ctx, monkeypatch)
         K_plain = gpu_ctx.gram(dx)
         assert "wave2" not in gpu_ctx.stats()["second_kernel_name"]
     assert np.abs(K - K_ref).max() < TOL and np.array_equal(K, K.T) and np.abs(K - K_plain).max() < 1e-13
+
+
+@pytest.mark.parametrize("edge", ["4", "6", "8"])
+def test_edge_blocks_agree_with_the_plain_chain(built, monkeypatch, edge):
+    """The ends of the chain from the sets' edge blocks (QK_EDGE: the first and last k sites of every state contracted across their
+    physical legs, X = Ly^T conj(Lx) at the left, sum X . (Ry^T conj(Rx)) at the right) against the plain sweep and the oracle, on
+    ragged states whose environment behind the edge is anything from one tile to larger than the LDS buffer; symmetric and
+    rectangular Grams, complex overlaps included."""
+    import qml_cutensornet_amd as Q
+    from oracle import restatement as R
+    from qml_cutensornet_amd import engine
+
+    rng = np.random.default_rng(int(edge) + 5)
+    n = 26
+    caps = (300, 150, 96, 60, 33, 17, 200)
+    xs = [Q.random_mps(n, [min(2 ** min(k, n - k), c) for k in range(n + 1)], rng) for c in caps]
+    ys = [Q.random_mps(n, _ragged_profile(rng, n, c), rng) for c in (120, 40, 70)]
+    z_ref = np.array([[R.mps_inner(x.tensors, y.tensors) for x in xs] for y in ys])
+    K_ref = R.gram_from_mps([m.tensors for m in xs])
+    out = {}
+    for mode in ("0", edge):
+        monkeypatch.setenv("QK_EDGE", mode)
+        with engine.context(0) as ctx, ctx.upload(xs) as dx, ctx.upload(ys) as dy:
+            out[mode] = (ctx.gram(dx), ctx.overlaps(dx, dy), dx.info()["device_bytes"])
+            assert "fused" in ctx.stats()["kernel_name"]
+    for mode in out:
+        assert np.abs(out[mode][0] - K_ref).max() < TOL and np.abs(out[mode][1] - z_ref).max() < TOL
+        assert np.array_equal(out[mode][0], out[mode][0].T)
+    assert np.abs(out[edge][0] - out["0"][0]).max() < 1e-13 and np.abs(out[edge][1] - out["0"][1]).max() < 1e-13
+    assert out[edge][2] > out["0"][2]  # the edge blocks are counted in the set's device bytes

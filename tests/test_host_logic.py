@@ -391,6 +391,29 @@ def test_tiled_plan_xcd_queues(built, monkeypatch, world, symmetric):
         assert max(costs) / min(costs) < 1.03
 
 
+def test_planner_chooses_the_edge_sites(built, monkeypatch):
+    """X1, the ends of the chain: the planner takes as many sites from per-state edge blocks as its cost model says pays (bonds that
+    still grow like 2^k: contracting across the physical legs is cheaper than walking the chain), none for short chains or when
+    QK_EDGE=0, exactly k when QK_EDGE=k; the algorithmic work of the plan does not depend on it."""
+    from qml_cutensornet_amd import engine
+
+    n = 40
+    grow = np.array([[min(2 ** min(k, n - k), c) for k in range(n + 1)] for c in (120, 200, 64, 90, 150)], dtype=np.int32)
+    p = engine.Plan(grow)
+    k_auto, flops = p.edge_sites, p.stats()["flops"]
+    p.close()
+    assert 6 <= k_auto <= 9  # bonds double up to site 6-7: that is where the chain gets expensive
+    short = np.array([[min(2 ** min(k, 8 - k), 16) for k in range(9)]] * 3, dtype=np.int32)
+    p = engine.Plan(short)
+    assert p.edge_sites == 0  # 8 sites: nothing to gain (and 2 k + 2 sites are needed)
+    p.close()
+    for env, want in (("0", 0), ("5", 5), ("99", 0)):
+        monkeypatch.setenv("QK_EDGE", env)
+        p = engine.Plan(grow)
+        assert p.edge_sites == want and p.stats()["flops"] == flops
+        p.close()
+
+
 def test_plan_work_model(built):
     from qml_cutensornet_amd import engine
 

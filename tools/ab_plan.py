@@ -34,7 +34,7 @@ def main():
     xset = ctx.upload(states)
     ref = None
     for st in settings:
-        for k in ("QK_PLAN_XCD", "QK_PLAN_TILE", "QK_FUSED_SPLIT", "QK_PLAN_SPLIT"):
+        for k in ("QK_PLAN_XCD", "QK_PLAN_TILE", "QK_FUSED_SPLIT", "QK_PLAN_SPLIT", "QK_EDGE"):
             os.environ.pop(k, None)
         for kv in st:
             k, v = kv.split("=")
@@ -50,7 +50,7 @@ def main():
         if ref is None:
             ref = K
         err = float(np.abs(K - ref).max())
-        print(f"{' '.join(st):32s} kernel {np.mean(ms):8.2f} ms (second launch {np.mean(ms2):7.2f}), tail {np.mean(tf):.4f} / {np.mean(tf2):.4f}, queues {s_['queues']}, {s_['kernel_name']}; max |K - K_first| {err:.2e}", flush=True)
+        print(f"{' '.join(st):32s} kernel {np.mean(ms):8.2f} ms (second launch {np.mean(ms2):7.2f}), tail {np.mean(tf):.4f} / {np.mean(tf2):.4f}, queues {s_['queues']}, edge sites {job.plan.edge_sites}, {s_['kernel_name']}; max |K - K_first| {err:.2e}", flush=True)
         job.close()
     xset.close()
     ctx.close()
