@@ -210,6 +210,13 @@ int qk_plan_queues(const qk_plan* plan, int64_t* qstart /* [17] */);
  * end; counted by qk_mps_set_info).  This is the host-side choice of the contraction order at the ends of the chain (north star;
  * reference call site G:380); the algorithmic flop count of qk_stats does not change.                                        */
 int32_t qk_plan_edge_sites(const qk_plan* plan);
+/* MERGED STEPS (no entry point: part of qk_gram_values; QK_MERGE=0 disables).  Between the edge blocks the site-fused sweep may walk
+ * two neighbouring sites as ONE step: the set holds, beside its plain image, the chain's sites contracted in twos over the bond between
+ * them (tensors [l][4][r], made once per set on first use and counted by qk_mps_set_info), and a workgroup decides per pair and step:
+ * the merged tensor where that keeps an LDS-resident step in the LDS and costs no more padded work than the two sites, the two plain
+ * sites otherwise (a dip of the bond).  Same matrix work where the bonds are level, half the barriers, set-ups and stream turn-arounds;
+ * again a host-prepared choice of the contraction order (reference call site G:380).  qk_stats' algorithmic flops and bytes stay those
+ * of the plain chain.                                                                                                          */
 
 /* ---- the hot path -----------------------------------------------------------
  * qk_gram_values: for every pair p of the plan compute z_p = <x_i|y_j> and write

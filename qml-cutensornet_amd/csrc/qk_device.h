@@ -41,6 +41,15 @@ struct SweepArgs {
   const double* yedge;
   const long long* yedge_offs;
   int edge_k;
+  // MERGED STEPS (site-fused sweep; merge_steps = 0: none): xmg / ymg hold, per state, the chain's sites [edge_k, n - edge_k) contracted
+  // in twos -- tensors [l][4][r], physical index 2 p1 + p2, interleaved complex, offsets (doubles) in x/ymg_offs[state][merge_steps],
+  // merge_steps = (n - 2 edge_k) / 2.  A workgroup decides per pair and per step whether it walks the merged tensor (half the barriers,
+  // set-ups and load latencies for the same matrix work when the bonds are level) or the two plain sites (qk_fused.h: qkf_step_table).
+  const double* xmg;
+  const double* ymg;
+  const int64_t* xmg_offs;
+  const int64_t* ymg_offs;
+  int merge_steps;
   unsigned long long* tail;     // per-launch device clocks (s_memrealtime, 100 MHz): [0] first workgroup start, [1] first workgroup exit, [4] last workgroup exit
   unsigned long long* prof;  // diagnostic build only: cycle sums per section (see QK_VARIANT=9)
   int debug_flags;           // timing experiments only (QK_DEBUG_FLAGS): bit 0 = skip epilogue stores, bit 1 = skip steady-state fetch/stash, bit 2 = skip MFMAs, bit 3 = skip steady-state barriers (all give WRONG results)

@@ -254,12 +254,72 @@ __device__ __forceinline__ void qkf_edge_suffix(const SweepArgs& g, const int xi
 
 // What a site needs: bonds, tile counts, where its X / X' live and how its items are cut into strips.
 struct QkfSite {
-  int a, a2, b, b2, at, nks, mt, nt, nn, W, inv;  // inv = ceil(2^20 / mt): u / mt == (u * inv) >> 20 for u < 2048, mt <= 32 (checked exhaustively)
+  int a, a2, b, b2, at, nks, mt, nt, nn, W, inv, pd, ps, next;  // next = the table entry of the step after this one; pd = physical dimension of the step (2, or 4 for two merged sites), ps = log2 pd; inv = ceil(2^20 / mt): u / mt == (u * inv) >> 20 for u < 2048, mt <= 32 (checked exhaustively)
   bool small;
   const v2d *Ak, *Bk;
 };
 typedef int v4i __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) v4i lds_v4i;
+
+// The step table of a pair, built by all threads at pair set-up: per step 12 ints (48 bytes)
+//   [0] a  [1] a2  [2] b  [3] b2  [4] true a  [5] k-steps of b  [6] W  [7] small  [8] ceil(2^20 / mt)  [9] log2 pd  [10] next step  [11] -
+// and the addresses of the step's two tensors ([a][pd][a2] of x, [b][pd][b2] of y) in a second table.  A step is one site (pd = 2,
+// entry = the site's index, next = + 1) or, with a merged image (SweepArgs.merge_steps), two sites contracted into one tensor of
+// physical dimension 4 (entry = the first site's index, next = + 2).  The merged step does the same matrix work as its two sites when
+// the bond between them is as large as the bonds around them, with half the barriers, set-ups and stream turn-arounds; it is taken
+// unless it would push an LDS-resident pair of sites out of the LDS (its 4 mt nt items no longer fit one round, and X and X' do not
+// fit side by side) or cost more padded work than the two sites (a dip of the bond between them).  `one_round(pd * mt, nt)`:
+// the kernel's test that a single round holds all items of a step.
+template <int XCAP, int NT, typename OneRound>
+__device__ __forceinline__ void qkf_step_table(const SweepArgs& g, const int xi, const int yj, lds_v4i* const rec, long long* const m_off, const int tid, const OneRound one_round) {
+  const int ns = g.n_sites, n1 = ns + 1;
+  const int32_t* const xd = g.xdims + (long long)xi * n1;
+  const int32_t* const yd = g.ydims + (long long)yj * n1;
+  const int32_t* const xt = g.xtrue + (long long)xi * n1;
+  const int32_t* const yt = g.ytrue + (long long)yj * n1;
+  const v2d* const xdata = reinterpret_cast<const v2d*>(g.xdata);
+  const v2d* const ydata = reinterpret_cast<const v2d*>(g.ydata);
+  auto is_small = [&](const int a, const int a2, const int b, const int b2, const int pd) __attribute__((always_inline)) {
+    return a * b <= XCAP && a2 * b2 <= XCAP && (one_round(pd * (a / TILE), b2 / TILE) || a * b + a2 * b2 <= XCAP);
+  };
+  auto put = [&](const int e, const int a, const int a2, const int b, const int b2, const int ps, const int next, const bool small, const v2d* const A, const v2d* const B)
+                 __attribute__((always_inline)) {
+    const int mt = a / TILE, nt = b2 / TILE;
+    const int W = small ? nt : max(1, min(nt, XCAP / (TILE * a2)));  // X' in strips of W blocks of b' (the strip's rows must fit the LDS)
+    rec[3 * e] = (v4i){a, a2, b, b2};
+    rec[3 * e + 1] = (v4i){xt[e], (yt[e] + 3) >> 2, W, small ? 1 : 0};
+    rec[3 * e + 2] = (v4i){((1 << 20) + mt - 1) / mt, ps, next, 0};
+    m_off[2 * e] = (long long)A;
+    m_off[2 * e + 1] = (long long)B;
+  };
+  auto plain = [&](const int e, const int next) __attribute__((always_inline)) {
+    const int a = xd[e], a2 = xd[e + 1], b = yd[e], b2 = yd[e + 1];
+    put(e, a, a2, b, b2, 1, next, is_small(a, a2, b, b2, 2), xdata + (g.xoffs[(long long)xi * ns + e] >> 1), ydata + (g.yoffs[(long long)yj * ns + e] >> 1));
+  };
+  if (g.merge_steps == 0) {
+    for (int e = tid; e < ns; e += NT) plain(e, e + 1);
+    return;
+  }
+  const int ek = g.edge_k, k_hi = ns - ek;
+  for (int t = tid; 2 * t < k_hi - ek; t += NT) {
+    const int e = ek + 2 * t;
+    if (e + 1 >= k_hi) {  // the single last site of an odd chain
+      plain(e, e + 1);
+      continue;
+    }
+    const int a = xd[e], am = xd[e + 1], a2 = xd[e + 2], b = yd[e], bm = yd[e + 1], b2 = yd[e + 2];
+    const bool sm = is_small(a, a2, b, b2, 4);
+    const long long work_m = 4ll * a * b2 * (b + a2), work_p = 2ll * a * bm * (b + am) + 2ll * am * b2 * (bm + a2);
+    // (measured on the two headline sets, same box: allowing 1/8 or 1/4 more padded work per merged step loses what the saved barriers
+    // gain -- 397.4 / 400.0 against 395.7 ms; merging LDS-resident steps only when that saves 6 % of the work: 406 ms)
+    const bool merged = (sm || (!is_small(a, am, b, bm, 2) && !is_small(am, a2, bm, b2, 2))) && work_m <= work_p;
+    plain(e + 1, e + 2);
+    if (merged)
+      put(e, a, a2, b, b2, 2, e + 2, sm, reinterpret_cast<const v2d*>(g.xmg) + (g.xmg_offs[(long long)xi * g.merge_steps + t] >> 1),
+          reinterpret_cast<const v2d*>(g.ymg) + (g.ymg_offs[(long long)yj * g.merge_steps + t] >> 1));
+    else plain(e, e + 1);
+  }
+}
 
 template <int NW, int S, int XCAP, int WPS>  // waves per workgroup; T slots per wave (a round holds NW * S items); elements of the LDS X buffer; waves per SIMD (register budget)
 __global__ __launch_bounds__(64 * NW, WPS) void qk_sweep_fused_kernel(const SweepArgs g) {
@@ -267,16 +327,12 @@ __global__ __launch_bounds__(64 * NW, WPS) void qk_sweep_fused_kernel(const Swee
   extern __shared__ __attribute__((aligned(16))) double lds_raw[];
   lds_v2d* const XL = (lds_v2d*)lds_raw;  // (a C-style cast: the generic -> LDS address-space cast)
   long long* const slot = reinterpret_cast<long long*>(lds_raw + 2 * XCAP);
-  const v2d* const xdata = reinterpret_cast<const v2d*>(g.xdata);  // interleaved complex128 images
-  const v2d* const ydata = reinterpret_cast<const v2d*>(g.ydata);
   v2d* const G0 = reinterpret_cast<v2d*>(g.scratch) + (long long)blockIdx.x * 2 * g.x_plane;  // two global X buffers of x_plane complex
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int j = lane & 15, q = lane >> 4;
-  const int ns = g.n_sites, n1 = ns + 1;
-  // per-site records of the current pair, built by all threads at pair set-up: 12 ints (48 bytes) per site
-  //   [0] a  [1] a2  [2] b  [3] b2  [4] true a  [5] k-steps of b  [6] W  [7] small  [8] ceil(2^20 / mt)  [9] -  [10..11] -
-  // and the two tensor offsets (elements of the interleaved image) as int64 in a second table
+  const int ns = g.n_sites;
+  // the step table of the current pair (qkf_step_table): 12 ints per step, and the addresses of the step's two tensors in a second table
   __attribute__((address_space(3))) double* const zacc = (__attribute__((address_space(3))) double*)(slot + 2);  // the overlap's two doubles (edge blocks)
   lds_v4i* const rec = (lds_v4i*)(slot + 4);
   long long* const m_off = reinterpret_cast<long long*>(slot + 4) + 6 * (long long)ns;  // [ns][2]: A_k, B_k
@@ -293,19 +349,20 @@ __global__ __launch_bounds__(64 * NW, WPS) void qk_sweep_fused_kernel(const Swee
     s.a = rfl(r0.x), s.a2 = rfl(r0.y), s.b = rfl(r0.z), s.b2 = rfl(r0.w);
     s.at = rfl(r1.x), s.nks = rfl(r1.y), s.W = rfl(r1.z), s.small = rfl(r1.w) != 0;
     s.inv = rfl(r2.x);
+    s.ps = rfl(r2.y), s.pd = 1 << s.ps, s.next = rfl(r2.z);
     s.mt = s.a / TILE, s.nt = s.b2 / TILE, s.nn = s.a2 / TILE;
-    s.Ak = xdata + ldl(m_off + 2 * k);      // [a][2][a2]
-    s.Bk = ydata + ldl(m_off + 2 * k + 1);  // [b][2][b2]
+    s.Ak = reinterpret_cast<const v2d*>(ldl(m_off + 2 * k));      // [a][pd][a2]
+    s.Bk = reinterpret_cast<const v2d*>(ldl(m_off + 2 * k + 1));  // [b][pd][b2]
     return s;
   };
   // the streams of item `it` of a strip starting at block s0 (it = 2 (tbl * mt + ta) + p)
   auto b_stream = [&](const QkfSite& s, const int s0, const int it) __attribute__((always_inline)) {
-    const int pp = it & 1, u = it >> 1, tbl = (u * s.inv) >> 20;
-    return QkfStream{s.Bk + pp * s.b2, (unsigned)((q * 2) * s.b2 + (s0 + tbl) * TILE + j), 8 * s.b2};
+    const int pp = it & (s.pd - 1), u = it >> s.ps, tbl = (u * s.inv) >> 20;
+    return QkfStream{s.Bk + pp * s.b2, (unsigned)((q * s.pd) * s.b2 + (s0 + tbl) * TILE + j), 4 * s.pd * s.b2};
   };
   auto a_stream = [&](const QkfSite& s, const int it) __attribute__((always_inline)) {
-    const int pp = it & 1, u = it >> 1, tbl = (u * s.inv) >> 20, ta = u - tbl * s.mt;
-    return QkfStream{s.Ak + pp * s.a2, (unsigned)(((ta * TILE + q) * 2) * s.a2 + j), 8 * s.a2};
+    const int pp = it & (s.pd - 1), u = it >> s.ps, tbl = (u * s.inv) >> 20, ta = u - tbl * s.mt;
+    return QkfStream{s.Ak + pp * s.a2, (unsigned)(((ta * TILE + q) * s.pd) * s.a2 + j), 4 * s.pd * s.a2};
   };
 #ifdef QKF_PROF  // experiment builds only: cycle sums per section of a wave's life (tools/fused_sections.py)
   unsigned long long pf[8] = {0, 0, 0, 0, 0, 0, 0, 0}, pt = __builtin_amdgcn_s_memtime();
@@ -328,29 +385,19 @@ __global__ __launch_bounds__(64 * NW, WPS) void qk_sweep_fused_kernel(const Swee
     __syncthreads();
     if (p < 0) break;
     const int xi = g.pairs[2 * p], yj = g.pairs[2 * p + 1];
-    for (int e = tid; e < ns; e += NT) {  // site e of the pair
-      const int a = g.xdims[(long long)xi * n1 + e], a2 = g.xdims[(long long)xi * n1 + e + 1];
-      const int b = g.ydims[(long long)yj * n1 + e], b2 = g.ydims[(long long)yj * n1 + e + 1];
-      const int mt = a / TILE, nt = b2 / TILE;
-      // an item is (ta, tb, p): 2 mt nt of them.  LDS-resident site: X and X' fit the buffer and either ONE round holds all items
-      // (X' may then overwrite X) or X and X' fit side by side (any number of rounds: X stays intact);
-      // otherwise X' is built in strips of W blocks of b' (the strip's rows must fit the LDS), items in rounds of NW * S
-      const int small = a * b <= XCAP && a2 * b2 <= XCAP && (2 * mt * nt <= NW * S || a * b + a2 * b2 <= XCAP);
-      const int W = small ? nt : max(1, min(nt, XCAP / (TILE * a2)));
-      rec[3 * e] = (v4i){a, a2, b, b2};
-      rec[3 * e + 1] = (v4i){g.xtrue[(long long)xi * n1 + e], (g.ytrue[(long long)yj * n1 + e] + 3) >> 2, W, small};
-      rec[3 * e + 2] = (v4i){((1 << 20) + mt - 1) / mt, 0, 0, 0};
-      m_off[2 * e] = g.xoffs[(long long)xi * ns + e] >> 1;
-      m_off[2 * e + 1] = g.yoffs[(long long)yj * ns + e] >> 1;
-    }
+    // an item is (ta, tb, p): pd mt nt of them.  LDS-resident step: X and X' fit the buffer and either ONE round holds all items
+    // (X' may then overwrite X) or X and X' fit side by side (any number of rounds: X stays intact);
+    // otherwise X' is built in strips of W blocks of b' (the strip's rows must fit the LDS), items in rounds of NW * S
+    qkf_step_table<XCAP, NT>(g, xi, yj, rec, m_off, tid, [](const int pmt, const int nt) { return pmt * nt <= NW * S; });
     const int ek = g.edge_k, k_hi = ns - ek;  // the chain runs over the sites [ek, k_hi): the ends are in the edge blocks
-    if (ek == 0)
+    const bool edges = ek > 0;
+    if (!edges)
       for (int e = tid; e < TILE * TILE; e += NT) XL[e] = (v2d){e == 0 ? 1.0 : 0.0, 0.0};  // X_0 = 1 in a 16 x 16 block
     if (tid == 0) zacc[0] = 0.0, zacc[1] = 0.0;
     __syncthreads();
     bool xg = false;  // where X lives: LDS (at element xb, row stride a) or the global buffer G0 + cur * x_plane
     int cur = 0, xb = 0;
-    if (ek > 0) {  // X behind the left edge: one product of the two left blocks
+    if (edges) {  // X behind the left edge: one product of the two left blocks
       const v4i r0 = rec[3 * ek];
       const int a_e = rfl(r0.x), b_e = rfl(r0.z);
       if (a_e * b_e <= XCAP) qkf_edge_prefix<NW>(g, xi, yj, a_e, b_e, XL, wave, q, j);
@@ -362,9 +409,10 @@ __global__ __launch_bounds__(64 * NW, WPS) void qk_sweep_fused_kernel(const Swee
     v2d fr[4];            // the fragment registers of the wave's global stream: they carry its next group across tiles and barriers
     bool primed = false;  // fr holds the first group of the wave's next tile
     QkfSite sn = site(ek);
-    for (int k = ek; k < k_hi; ++k) {
+    for (int k = ek; k < k_hi;) {
       const QkfSite sc = sn;
-      if (k + 1 < k_hi) sn = site(k + 1);
+      k = sc.next;  // (from here on: the entry of the NEXT step)
+      if (k < k_hi) sn = site(k);
       const int a = sc.a, a2 = sc.a2, b = sc.b, mt = sc.mt, nt = sc.nt, W = sc.W;
       const bool small = sc.small;
       v2d* const Gc = G0 + (long long)cur * g.x_plane;
@@ -389,7 +437,7 @@ __global__ __launch_bounds__(64 * NW, WPS) void qk_sweep_fused_kernel(const Swee
         for (int e = tid; e < n_out; e += NT) XL[ob + e] = (v2d){0.0, 0.0};
       QKF_STAMP(1);  // X moved between LDS and the global buffer
       for (int s0 = 0; s0 < nt; s0 += W) {
-        const int w = min(W, nt - s0), items = 2 * mt * w;
+        const int w = min(W, nt - s0), items = sc.pd * mt * w;
         if (!small) {  // zero this strip's X' rows (the LDS-resident path zeroes after phase 1: X is still being read)
           for (int e = tid; e < w * TILE * a2; e += NT) XL[e] = (v2d){0.0, 0.0};
           qk_lds_barrier();
@@ -406,7 +454,7 @@ __global__ __launch_bounds__(64 * NW, WPS) void qk_sweep_fused_kernel(const Swee
               if (multi) qkf_rotate<S>(T, L);
               const int it = it0 + NW * s;
               if (it < items) {
-                const int u = it >> 1, tbl = (u * sc.inv) >> 20, ta = u - tbl * mt;
+                const int u = it >> sc.ps, tbl = (u * sc.inv) >> 20, ta = u - tbl * mt;
                 const bool more = s + 1 < L && it + NW < items;  // another tile follows in this phase; else phase 2 starts with item it0
                 const QkfStream nxt = more ? b_stream(sc, s0, it + NW) : a_stream(sc, it0);
                 qkf_p1_tile(T[S - 1], fr, primed, b_stream(sc, s0, it), xbase, (unsigned)(q * a + ta * TILE + j), 4 * a, sc.nks, nxt);
@@ -432,11 +480,11 @@ __global__ __launch_bounds__(64 * NW, WPS) void qk_sweep_fused_kernel(const Swee
             const int it = it0 + NW * s;
             if (it >= items) break;
             if (multi) qkf_rotate<S>(T, L);
-            const int u = it >> 1, tbl = (u * sc.inv) >> 20, ta = u - tbl * mt;
+            const int u = it >> sc.ps, tbl = (u * sc.inv) >> 20, ta = u - tbl * mt;
             const int kmax = min(4, (sc.at - ta * TILE + 3) >> 2);
             const bool more = s + 1 < S && it + NW < items;
             // after the wave's last item of the site: its first tile of the next site (strip 0, round 0), if it has one
-            const bool chain = !more && last_round && k + 1 < k_hi && wave < 2 * sn.mt * min(sn.W, sn.nt);
+            const bool chain = !more && last_round && k < k_hi && wave < sn.pd * sn.mt * min(sn.W, sn.nt);
             const QkfStream nxt = more ? a_stream(sc, it + NW) : chain ? b_stream(sn, 0, wave) : a_stream(sc, it);
             if (kmax == 4) qkf_p2_item<true>(T[S - 1], fr, primed, a_stream(sc, it), a2, sc.nn, 4, XL + ob + tbl * TILE * a2, q, j, nxt);
             else qkf_p2_item<false>(T[S - 1], fr, primed, a_stream(sc, it), a2, sc.nn, kmax, XL + ob + tbl * TILE * a2, q, j, nxt);
@@ -459,7 +507,7 @@ __global__ __launch_bounds__(64 * NW, WPS) void qk_sweep_fused_kernel(const Swee
         xb = ob;
       }
     }
-    if (ek > 0) {  // the overlap: X against the product of the two right blocks
+    if (edges) {  // the overlap: X against the product of the two right blocks
       const v4i r0 = rec[3 * (k_hi - 1)];
       const int a_e = rfl(r0.y), b_e = rfl(r0.w);
       if (xg) qkf_edge_suffix<NW>(g, xi, yj, a_e, b_e, (const v2d*)(G0 + (long long)cur * g.x_plane), zacc, wave, q, j);
@@ -467,7 +515,7 @@ __global__ __launch_bounds__(64 * NW, WPS) void qk_sweep_fused_kernel(const Swee
       __syncthreads();
     }
     if (tid == 0) {
-      const v2d zz = ek > 0 ? (v2d){zacc[0], zacc[1]} : xg ? G0[(long long)cur * g.x_plane] : (v2d)XL[xb];
+      const v2d zz = edges ? (v2d){zacc[0], zacc[1]} : xg ? G0[(long long)cur * g.x_plane] : (v2d)XL[xb];
       g.values[p] = zz.x * zz.x + zz.y * zz.y;
       if (g.z) {
         g.z[2 * p] = zz.x;
@@ -583,13 +631,11 @@ __global__ __launch_bounds__(64 * NW, WPS) void qk_sweep_fused_dual_kernel(const
   extern __shared__ __attribute__((aligned(16))) double lds_raw[];
   lds_v2d* const XL = (lds_v2d*)lds_raw;
   long long* const slot = reinterpret_cast<long long*>(lds_raw + 2 * XCAP);
-  const v2d* const xdata = reinterpret_cast<const v2d*>(g.xdata);
-  const v2d* const ydata = reinterpret_cast<const v2d*>(g.ydata);
   v2d* const G0 = reinterpret_cast<v2d*>(g.scratch) + (long long)blockIdx.x * 2 * g.x_plane;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int j = lane & 15, q = lane >> 4;
-  const int ns = g.n_sites, n1 = ns + 1;
+  const int ns = g.n_sites;
   __attribute__((address_space(3))) double* const zacc = (__attribute__((address_space(3))) double*)(slot + 2);
   lds_v4i* const rec = (lds_v4i*)(slot + 4);  // per-site records as in qk_sweep_fused_kernel
   long long* const m_off = reinterpret_cast<long long*>(slot + 4) + 6 * (long long)ns;
@@ -606,15 +652,16 @@ __global__ __launch_bounds__(64 * NW, WPS) void qk_sweep_fused_dual_kernel(const
     s.a = rfl(r0.x), s.a2 = rfl(r0.y), s.b = rfl(r0.z), s.b2 = rfl(r0.w);
     s.at = rfl(r1.x), s.nks = rfl(r1.y), s.W = rfl(r1.z), s.small = rfl(r1.w) != 0;
     s.inv = rfl(r2.x);
+    s.ps = rfl(r2.y), s.pd = 1 << s.ps, s.next = rfl(r2.z);
     s.mt = s.a / TILE, s.nt = s.b2 / TILE, s.nn = s.a2 / TILE;
-    s.Ak = xdata + ldl(m_off + 2 * k);
-    s.Bk = ydata + ldl(m_off + 2 * k + 1);
+    s.Ak = reinterpret_cast<const v2d*>(ldl(m_off + 2 * k));
+    s.Bk = reinterpret_cast<const v2d*>(ldl(m_off + 2 * k + 1));
     return s;
   };
   // the streams of pair `v` of a strip starting at block s0 (v = 2 (tp * mt + ta) + p; column blocks s0 + 2 tp, + 1)
   auto b_stream = [&](const QkfSite& s, const int s0, const int v, const int half) __attribute__((always_inline)) {
-    const int pp = v & 1, u = v >> 1, tp = (u * s.inv) >> 20;
-    return QkfStream{s.Bk + pp * s.b2, (unsigned)((q * 2) * s.b2 + (s0 + 2 * tp + half) * TILE + j), 8 * s.b2};
+    const int pp = v & (s.pd - 1), u = v >> s.ps, tp = (u * s.inv) >> 20;
+    return QkfStream{s.Bk + pp * s.b2, (unsigned)((q * s.pd) * s.b2 + (s0 + 2 * tp + half) * TILE + j), 4 * s.pd * s.b2};
   };
   // What this wave does in the round that starts at unit r0 of a strip of w blocks with `units` pairs of tiles: pair r0 + wave
   // -- or, when the units left fill at most half of the waves, ONE tile of a pair (column block 2 tp or 2 tp + 1):
@@ -630,15 +677,15 @@ __global__ __launch_bounds__(64 * NW, WPS) void qk_sweep_fused_dual_kernel(const
     // (first tiles to waves 0 .. left - 1, second tiles to the next `left` waves: consecutive waves sit on different SIMDs)
     un.half = (halves && wave >= left) ? 1 : 0;
     un.v = r0 + wave - (un.half ? left : 0);
-    const int tp = ((un.v >> 1) * s.inv) >> 20;
+    const int tp = ((un.v >> s.ps) * s.inv) >> 20;
     const bool second = 2 * tp + 1 < w;  // the pair has a second tile
     un.mine = un.v < units && (un.half == 0 || second);
     un.has1 = !halves && second;
     return un;
   };
   auto a_stream = [&](const QkfSite& s, const int v) __attribute__((always_inline)) {
-    const int pp = v & 1, u = v >> 1, tp = (u * s.inv) >> 20, ta = u - tp * s.mt;
-    return QkfStream{s.Ak + pp * s.a2, (unsigned)(((ta * TILE + q) * 2) * s.a2 + j), 8 * s.a2};
+    const int pp = v & (s.pd - 1), u = v >> s.ps, tp = (u * s.inv) >> 20, ta = u - tp * s.mt;
+    return QkfStream{s.Ak + pp * s.a2, (unsigned)(((ta * TILE + q) * s.pd) * s.a2 + j), 4 * s.pd * s.a2};
   };
   const int xcc = qk_xcc_id();
   if (tid == 0) qk_tail_start(g);
@@ -649,28 +696,18 @@ __global__ __launch_bounds__(64 * NW, WPS) void qk_sweep_fused_dual_kernel(const
     __syncthreads();
     if (p < 0) break;
     const int xi = g.pairs[2 * p], yj = g.pairs[2 * p + 1];
-    for (int e = tid; e < ns; e += NT) {
-      const int a = g.xdims[(long long)xi * n1 + e], a2 = g.xdims[(long long)xi * n1 + e + 1];
-      const int b = g.ydims[(long long)yj * n1 + e], b2 = g.ydims[(long long)yj * n1 + e + 1];
-      const int mt = a / TILE, nt = b2 / TILE;
-      // a unit is (ta, tp, p): 2 mt ceil(nt / 2) pairs of tiles.  LDS-resident site: X and X' fit the buffer and ONE round holds
-      // all pairs, or they fit side by side; otherwise X' is built in strips of W blocks of b', pairs in rounds of NW
-      const int small = a * b <= XCAP && a2 * b2 <= XCAP && (2 * mt * ((nt + 1) / 2) <= NW || a * b + a2 * b2 <= XCAP);
-      const int W = small ? nt : max(1, min(nt, XCAP / (TILE * a2)));  // (an odd strip ends in a single tile)
-      rec[3 * e] = (v4i){a, a2, b, b2};
-      rec[3 * e + 1] = (v4i){g.xtrue[(long long)xi * n1 + e], (g.ytrue[(long long)yj * n1 + e] + 3) >> 2, W, small};
-      rec[3 * e + 2] = (v4i){((1 << 20) + mt - 1) / mt, 0, 0, 0};
-      m_off[2 * e] = g.xoffs[(long long)xi * ns + e] >> 1;
-      m_off[2 * e + 1] = g.yoffs[(long long)yj * ns + e] >> 1;
-    }
+    // a unit is (ta, tp, p): pd mt ceil(nt / 2) pairs of tiles.  LDS-resident step: X and X' fit the buffer and ONE round holds
+    // all pairs, or they fit side by side; otherwise X' is built in strips of W blocks of b', pairs in rounds of NW
+    qkf_step_table<XCAP, NT>(g, xi, yj, rec, m_off, tid, [](const int pmt, const int nt) { return pmt * ((nt + 1) / 2) <= NW; });
     const int ek = g.edge_k, k_hi = ns - ek;  // the chain runs over the sites [ek, k_hi): the ends are in the edge blocks
-    if (ek == 0)
+    const bool edges = ek > 0;
+    if (!edges)
       for (int e = tid; e < TILE * TILE; e += NT) XL[e] = (v2d){e == 0 ? 1.0 : 0.0, 0.0};
     if (tid == 0) zacc[0] = 0.0, zacc[1] = 0.0;
     __syncthreads();
     bool xg = false;
     int cur = 0, xb = 0;
-    if (ek > 0) {  // X behind the left edge: one product of the two left blocks
+    if (edges) {  // X behind the left edge: one product of the two left blocks
       const v4i r0 = rec[3 * ek];
       const int a_e = rfl(r0.x), b_e = rfl(r0.z);
       if (a_e * b_e <= XCAP) qkf_edge_prefix<NW>(g, xi, yj, a_e, b_e, XL, wave, q, j);
@@ -681,9 +718,10 @@ __global__ __launch_bounds__(64 * NW, WPS) void qk_sweep_fused_dual_kernel(const
     v2d fr[4], fs[4];     // the fragment registers of the wave's global streams (fs: the second column block of phase 1)
     bool primed = false;  // fr / fs hold the first group of the wave's next pair of tiles
     QkfSite sn = site(ek);
-    for (int k = ek; k < k_hi; ++k) {
+    for (int k = ek; k < k_hi;) {
       const QkfSite sc = sn;
-      if (k + 1 < k_hi) sn = site(k + 1);
+      k = sc.next;  // (from here on: the entry of the NEXT step)
+      if (k < k_hi) sn = site(k);
       const int a = sc.a, a2 = sc.a2, b = sc.b, mt = sc.mt, nt = sc.nt, W = sc.W;
       const bool small = sc.small;
       v2d* const Gc = G0 + (long long)cur * g.x_plane;
@@ -703,7 +741,7 @@ __global__ __launch_bounds__(64 * NW, WPS) void qk_sweep_fused_dual_kernel(const
       if (pingpong)
         for (int e = tid; e < n_out; e += NT) XL[ob + e] = (v2d){0.0, 0.0};
       for (int s0 = 0; s0 < nt; s0 += W) {
-        const int w = min(W, nt - s0), units = 2 * mt * ((w + 1) >> 1);
+        const int w = min(W, nt - s0), units = sc.pd * mt * ((w + 1) >> 1);
         if (!small) {
           for (int e = tid; e < w * TILE * a2; e += NT) XL[e] = (v2d){0.0, 0.0};
           qk_lds_barrier();
@@ -712,7 +750,7 @@ __global__ __launch_bounds__(64 * NW, WPS) void qk_sweep_fused_dual_kernel(const
           const Unit un = unit_of(sc, w, units, r0);
           const int v = un.v;
           const bool mine = un.mine, has1 = un.has1;
-          const int u = v >> 1, tp = (u * sc.inv) >> 20, ta = u - tp * mt;
+          const int u = v >> sc.ps, tp = (u * sc.inv) >> 20, ta = u - tp * mt;
           if (mine) {
             const QkfStream bs = b_stream(sc, s0, v, un.half), as = a_stream(sc, v);
             const unsigned xoff = (unsigned)(q * a + ta * TILE + j);
@@ -742,11 +780,11 @@ __global__ __launch_bounds__(64 * NW, WPS) void qk_sweep_fused_dual_kernel(const
               if (nu.mine) nxt = b_stream(sc, s0, nu.v, nu.half), np1 = true;
             } else if (s0 + W < nt) {
               const int w2 = min(W, nt - s0 - W);
-              const Unit nu = unit_of(sc, w2, 2 * mt * ((w2 + 1) >> 1), 0);
+              const Unit nu = unit_of(sc, w2, sc.pd * mt * ((w2 + 1) >> 1), 0);
               if (nu.mine) nxt = b_stream(sc, s0 + W, nu.v, nu.half), np1 = true;
-            } else if (k + 1 < k_hi) {
+            } else if (k < k_hi) {
               const int w2 = min(sn.W, sn.nt);
-              const Unit nu = unit_of(sn, w2, 2 * sn.mt * ((w2 + 1) >> 1), 0);
+              const Unit nu = unit_of(sn, w2, sn.pd * sn.mt * ((w2 + 1) >> 1), 0);
               if (nu.mine) nxt = b_stream(sn, 0, nu.v, nu.half), np1 = true;
             }
             const unsigned nd1 = 0;
@@ -774,7 +812,7 @@ __global__ __launch_bounds__(64 * NW, WPS) void qk_sweep_fused_dual_kernel(const
         xb = ob;
       }
     }
-    if (ek > 0) {  // the overlap: X against the product of the two right blocks
+    if (edges) {  // the overlap: X against the product of the two right blocks
       const v4i r0 = rec[3 * (k_hi - 1)];
       const int a_e = rfl(r0.y), b_e = rfl(r0.w);
       if (xg) qkf_edge_suffix<NW>(g, xi, yj, a_e, b_e, (const v2d*)(G0 + (long long)cur * g.x_plane), zacc, wave, q, j);
@@ -782,7 +820,7 @@ __global__ __launch_bounds__(64 * NW, WPS) void qk_sweep_fused_dual_kernel(const
       __syncthreads();
     }
     if (tid == 0) {
-      const v2d zz = ek > 0 ? (v2d){zacc[0], zacc[1]} : xg ? G0[(long long)cur * g.x_plane] : (v2d)XL[xb];
+      const v2d zz = edges ? (v2d){zacc[0], zacc[1]} : xg ? G0[(long long)cur * g.x_plane] : (v2d)XL[xb];
       g.values[p] = zz.x * zz.x + zz.y * zz.y;
       if (g.z) {
         g.z[2 * p] = zz.x;
@@ -900,6 +938,7 @@ __global__ __launch_bounds__(64, 2) void qk_sweep_wave2_kernel(const SweepArgs g
       // (pinned to scalar registers: left alone, the compiler folds the two true-bond loads and the per-lane select below into
       //  ONE per-lane vector load -- and the s_waitcnt vmcnt(0) behind it drains the LDS-DMAs in flight at every site)
       const int fa = xd[f_k], fb = yd[f_k], fat = __builtin_amdgcn_readfirstlane(xt[f_k]), fbt = __builtin_amdgcn_readfirstlane(yt[f_k]);
+      const int fat2 = __builtin_amdgcn_readfirstlane(xt[f_k + 1]), fbt2 = __builtin_amdgcn_readfirstlane(yt[f_k + 1]);
       f_a2 = xd[f_k + 1], f_b2 = yd[f_k + 1];
       f_A = xdata + (xo[f_k] >> 1) * ES, f_B = ydata + (yo[f_k] >> 1) * ES;
       const int kb = fb >> 4, nn = f_a2 >> 4, mt = fa >> 4, nt = f_b2 >> 4, gpb = kb + nn;
@@ -909,17 +948,23 @@ __global__ __launch_bounds__(64, 2) void qk_sweep_wave2_kernel(const SweepArgs g
       const bool is_b = h < kb;
       const int off = is_b ? ((h * TILE) * 2 + pp) * f_b2 + tb * TILE : ((ta * TILE) * 2 + pp) * f_a2 + (h - kb) * TILE;
       const int cnt = is_b ? min(4, (fbt - h * TILE + 3) >> 2) : min(4, (fat - ta * TILE + 3) >> 2);
-      desc = off | (cnt << 16) | ((is_b ? 1 : 0) << 20);
+      // columns of the group below the true bond, in fours (64 bytes of a row): 1..4
+      const int cv4 = is_b ? min(4, (fbt2 - tb * TILE + 3) >> 2) : min(4, (fat2 - (h - kb) * TILE + 3) >> 2);
+      desc = off | (cnt << 16) | ((is_b ? 1 : 0) << 20) | (cv4 << 21);
       f_n = nt * mt * 2 * gpb, f_i = 0;
     };
     // fetch the next group: its k-steps below the true bond (the rows above are zero padding: a third of the image at bonds
     // around 20); the pieces above are asked for again at the address of the last one needed -- an L1 hit, no fabric bytes --
-    // so that every group is the same number of LDS-DMAs and the consumer's wait is a constant.
+    // so that every group is the same number of LDS-DMAs and the consumer's wait is a constant.  Of each row only the columns
+    // below the true bond, in fours (64 bytes), are asked for -- the lanes of the others sit the LDS-DMA out: at the bonds of
+    // 11..19 that fill the 100-qubit set, the 16-column padding of the rows is another fifth of the bytes.  Their places in the ring
+    // keep whatever was there: that reaches only the rows and columns of X' above the true bonds, which are cleared at the end
+    // of every site (below).
     auto issue = [&]() __attribute__((always_inline)) {
       if (f_k >= ns) return;
       const int d = __builtin_amdgcn_readlane(desc, f_i);
-      const int off = d & 0xffff, cnt = (d >> 16) & 7;
-      const bool is_b = (d >> 20) != 0;
+      const int off = d & 0xffff, cnt = (d >> 16) & 7, cv = ((d >> 21) & 7) * 4;
+      const bool is_b = ((d >> 20) & 1) != 0;
       const int ld = is_b ? f_b2 : f_a2;
       const char* const base = (is_b ? f_B : f_A) + (long)off * ES;
       if constexpr (F32) {
@@ -927,11 +972,13 @@ __global__ __launch_bounds__(64, 2) void qk_sweep_wave2_kernel(const SweepArgs g
         const char* const src = base + (((lane >> 3) * 2) * ld + (lane & 7) * 2) * ES;
         const int last = (cnt - 1) >> 1;
 #pragma unroll
-        for (int pc = 0; pc < 2; ++pc) __builtin_amdgcn_global_load_lds(src + (min(pc, last) * 16 * ld) * ES, (lds_ptr_t)(ring + f_slot * GROUP + pc * 64), 16, 0, 0);
+        for (int pc = 0; pc < 2; ++pc)
+          if ((lane & 7) * 2 < cv) __builtin_amdgcn_global_load_lds(src + (min(pc, last) * 16 * ld) * ES, (lds_ptr_t)(ring + f_slot * GROUP + pc * 64), 16, 0, 0);
       } else {
         const char* const src = base + ((q * 2) * ld + j) * ES;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) __builtin_amdgcn_global_load_lds(src + (min(i, cnt - 1) * 8 * ld) * ES, (lds_ptr_t)(ring + (f_slot * 4 + i) * 64), 16, 0, 0);
+        for (int i = 0; i < 4; ++i)
+          if (j < cv) __builtin_amdgcn_global_load_lds(src + (min(i, cnt - 1) * 8 * ld) * ES, (lds_ptr_t)(ring + (f_slot * 4 + i) * 64), 16, 0, 0);
       }
       f_slot = (f_slot == NG - 1) ? 0 : f_slot + 1;
       if (++f_i == f_n) {
@@ -1039,10 +1086,27 @@ __global__ __launch_bounds__(64, 2) void qk_sweep_wave2_kernel(const SweepArgs g
           for (int tn = 0; tn < 2; ++tn) XN[tb][tn].re = n1a[tn] + n2a[tn], XN[tb][tn].im = n3a[tn] - n1a[tn] + n2a[tn];
         }
       }
+      if constexpr (NG > 0) {
+        // X' above the true bonds (in fours: the columns in between were fetched, and are zero) holds what the skipped lanes of
+        // the LDS-DMAs left in the ring: cleared here, so that it meets nothing but cleared rows at the next site
+        const int am = (xt[k + 1] + 3) & ~3, bm = (yt[k + 1] + 3) & ~3;
 #pragma unroll
-      for (int u = 0; u < 2; ++u)
+        for (int u = 0; u < 2; ++u)
 #pragma unroll
-        for (int v = 0; v < 2; ++v) XA[u][v] = XN[u][v];
+          for (int v = 0; v < 2; ++v) {
+            const bool col = v * TILE + j < am;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              const bool keep = col && (u * TILE + 4 * i + q < bm);
+              XA[u][v].re[i] = keep ? XN[u][v].re[i] : 0.0, XA[u][v].im[i] = keep ? XN[u][v].im[i] : 0.0;
+            }
+          }
+      } else {
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+          for (int v = 0; v < 2; ++v) XA[u][v] = XN[u][v];
+      }
     }
     {
       // z = X_n[0][0] sits in lane 0; broadcast and stored by every lane (see qk_sweep_wave_kernel for why)

@@ -36,6 +36,7 @@ struct qk_ctx {
   size_t scratch_bytes = 0;
   unsigned long long* counter = nullptr;  // work-queue heads (QK_NQ_MAX of them, QK_QSTRIDE apart) + 2 x 4 tail clocks behind them
   bool tail_pending = false;
+  bool merge_sites = true;  // QK_MERGE (0 disables): the site-fused sweep walks the chain in merged steps of two sites (qk_device.h: SweepArgs.merge_steps)
   unsigned long long* prof = nullptr;  // 8 cycle sums of the diagnostic variant
   int variant = 20;    // 20 = the shipped kernels.  Anything else exists only in libqklab.so (QK_VARIANT there: 17 = lean register-staged
                        // sweep; 0, 2, 12, 13, 14, 16, 21, 23 = other kernels kept for A/B; 9, 19 = instrumented)
@@ -72,6 +73,12 @@ struct qk_mps_set {
   long long* d_edge_offs = nullptr;  // [n_states][2] element offsets
   int edge_k = 0;
   int64_t edge_bytes = 0;
+  // merged image of the site-fused sweep (SweepArgs.merge_steps; made on first use for the plan's edge_k): the chain's sites [k, n - k)
+  // contracted in twos, interleaved complex [l][4][r]
+  double* d_mg = nullptr;
+  int64_t* d_mg_offs = nullptr;  // offsets in doubles [n_states][mg_steps]
+  int mg_k = -1, mg_steps = 0;
+  int64_t mg_bytes = 0;
 };
 
 struct qk_plan {

@@ -706,6 +706,45 @@ __global__ __launch_bounds__(256) void qk_edge_kernel(const double* __restrict__
   }
 }
 
+// Merged image of a set (SweepArgs.merge_steps; qk_fused.h): step t of state st = the chain's sites s = k + 2 t and s + 1 contracted over
+// the bond between them, M[l][2 p1 + p2][r] = sum_m A_s[l][p1][m] A_{s+1}[m][p2][r] (padded bonds; the padding of the planes is zero,
+// so is M's).  One workgroup per step at a time, a thread per (l, r) with the four physical combinations in registers; reads the
+// split planes, writes interleaved complex.  Once per set: not part of a sweep.
+__global__ __launch_bounds__(256) void qk_merge_kernel(const double* __restrict__ data, const int32_t* __restrict__ dims, const int64_t* __restrict__ offs, const int n_sites, const int k,
+                                                       const int steps, const long long n_states, qk_v2d* __restrict__ out, const int64_t* __restrict__ out_offs) {
+  const int n1 = n_sites + 1;
+  for (long long t = blockIdx.x; t < n_states * steps; t += gridDim.x) {
+    const long long st = t / steps;
+    const int step = (int)(t - st * steps), s_ = k + 2 * step;
+    const int32_t* d = dims + st * n1;
+    qk_v2d* const dst = out + (out_offs[t] >> 1);
+    const int lp = d[s_], mp = d[s_ + 1], rp = d[s_ + 2];
+    const double* re1 = data + offs[st * n_sites + s_];
+    const double* im1 = re1 + (long long)lp * 2 * mp;
+    const double* re2 = data + offs[st * n_sites + s_ + 1];
+    const double* im2 = re2 + (long long)mp * 2 * rp;
+    for (int e = threadIdx.x; e < lp * rp; e += blockDim.x) {
+      const int l = e / rp, r = e - l * rp;
+      double ar[4] = {0, 0, 0, 0}, ai[4] = {0, 0, 0, 0};
+      const double* a0r = re1 + (long long)(2 * l) * mp;  // A_s[l][0][.], [l][1][.] follows at + mp
+      const double* a0i = im1 + (long long)(2 * l) * mp;
+      for (int m = 0; m < mp; ++m) {
+        const double xr[2] = {a0r[m], a0r[mp + m]}, xi[2] = {a0i[m], a0i[mp + m]};
+        const long long o2 = (long long)(2 * m) * rp + r;  // A_{s+1}[m][0][r], [m][1][r] at + rp
+        const double yr[2] = {re2[o2], re2[o2 + rp]}, yi[2] = {im2[o2], im2[o2 + rp]};
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const int p1 = c >> 1, p2 = c & 1;
+          ar[c] += xr[p1] * yr[p2] - xi[p1] * yi[p2];
+          ai[c] += xr[p1] * yi[p2] + xi[p1] * yr[p2];
+        }
+      }
+#pragma unroll
+      for (int c = 0; c < 4; ++c) dst[(long long)(4 * l + c) * rp + r] = (qk_v2d){ar[c], ai[c]};
+    }
+  }
+}
+
 // self-test: C[16x16] = sum_{k<16} P[k][m] * Q[k][n] with the fragment maps used above
 __global__ void qk_selftest_f32_kernel(const float* __restrict__ P, const float* __restrict__ Q, float* __restrict__ C) {
   const int lane = threadIdx.x & 63, j = lane & 15, q = lane >> 4;
@@ -731,6 +770,7 @@ extern "C" int qk_device_count(void) {
 }
 
 static int ctx_init(qk_ctx* c, int device_id, int num_cus);
+static void free_merged(qk_mps_set* m);
 
 extern "C" int qk_ctx_create(int device_id, qk_ctx** out) {
   if (!out) return fail(QK_EINVAL, "qk_ctx_create: null out");
@@ -785,6 +825,7 @@ static int ctx_init(qk_ctx* c, int device_id, int num_cus) {
   if (const char* v = std::getenv("QK_WAVE")) c->wave_path = std::atoi(v) != 0;
   if (const char* v = std::getenv("QK_WAVE2")) c->wave2_path = std::atoi(v) != 0, c->wave2_ring = std::atoi(v) != 2;
   if (const char* v = std::getenv("QK_FUSED")) c->fused_path = std::atoi(v);
+  if (const char* v = std::getenv("QK_MERGE")) c->merge_sites = std::atoi(v) != 0;
   // QK_DETERMINISTIC=1: bit-reproducible Grams.  The site-fused sweep sums the tiles of a column with LDS atomics in arrival
   // order (two launches on the same inputs differ in the last bits, <= 9e-16); the ring sweep, the small-bond sweep and the
   // one-wave sweeps add in a fixed order.  So the fused sweep is taken out of the selection (sets with a bond > 32 run the ring
@@ -919,6 +960,7 @@ extern "C" int qk_mps_set_destroy(qk_mps_set* m) {
   if (m->d_il) (void)hipFree(m->d_il);
   if (m->d_edge) (void)hipFree(m->d_edge);
   if (m->d_edge_offs) (void)hipFree(m->d_edge_offs);
+  free_merged(m);
   if (m->d_dims) (void)hipFree(m->d_dims);
   if (m->d_true) (void)hipFree(m->d_true);
   if (m->d_offs) (void)hipFree(m->d_offs);
@@ -931,7 +973,7 @@ extern "C" int qk_mps_set_info(const qk_mps_set* m, int32_t* n_states, int32_t* 
   if (n_states) *n_states = m->n_states;
   if (n_sites) *n_sites = m->n_sites;
   if (max_padded_bond) *max_padded_bond = m->max_pad;
-  if (device_bytes) *device_bytes = m->bytes * (m->d_il ? 2 : 1) + m->edge_bytes;  // the interleaved twin the fused / wave2 sweeps make on first use counts
+  if (device_bytes) *device_bytes = m->bytes * (m->d_il ? 2 : 1) + m->edge_bytes + m->mg_bytes;  // the interleaved twin the fused / wave2 sweeps make on first use counts
   return QK_OK;
 }
 
@@ -1086,6 +1128,42 @@ static int ensure_edges(qk_ctx* c, qk_mps_set* m, const int k) {
   return QK_OK;
 }
 
+static void free_merged(qk_mps_set* m) {
+  if (m->d_mg) (void)hipFree(m->d_mg);
+  if (m->d_mg_offs) (void)hipFree(m->d_mg_offs);
+  m->d_mg = nullptr, m->d_mg_offs = nullptr, m->mg_k = -1, m->mg_steps = 0, m->mg_bytes = 0;
+}
+
+// the merged image of a set for a chain that starts `k` sites in (made once per set and k; fp64 sets)
+static int ensure_merged(qk_ctx* c, qk_mps_set* m, const int k) {
+  if (m->d_mg && m->mg_k == k) return QK_OK;
+  free_merged(m);
+  const int n = m->n_sites, stride = n + 1, steps = (n - 2 * k) / 2;
+  if (steps < 1) return fail(QK_EINVAL, "ensure_merged: a chain of %d sites", n - 2 * k);
+  std::vector<int64_t> mo((size_t)m->n_states * steps);
+  long long total = 0;  // complex elements
+  for (int s_ = 0; s_ < m->n_states; ++s_) {
+    const int32_t* d = m->dims_true.data() + (size_t)s_ * stride;
+    for (int t = 0; t < steps; ++t) {
+      mo[(size_t)s_ * steps + t] = 2 * total;
+      total += 4ll * pad16(d[k + 2 * t]) * pad16(d[k + 2 * t + 2]);
+    }
+  }
+  DevBuf ib, ob;
+  HIP_TRY(ib.alloc((size_t)total * 2 * sizeof(double)));
+  HIP_TRY(ob.alloc(mo.size() * sizeof(int64_t)));
+  HIP_TRY(hipMemcpyAsync(ob.p, mo.data(), mo.size() * sizeof(int64_t), hipMemcpyHostToDevice, c->stream));
+  const long long tasks = (long long)m->n_states * steps;
+  qk_merge_kernel<<<dim3((unsigned)std::min<long long>(tasks, 16ll * c->num_cus)), dim3(256), 0, c->stream>>>(m->d_data, m->d_dims, m->d_offs, n, k, steps, m->n_states, ib.as<qk_v2d>(),
+                                                                                                                  ob.as<int64_t>());
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipStreamSynchronize(c->stream));  // (the host table goes out of scope; once per set)
+  m->d_mg = ib.as<double>(), m->d_mg_offs = ob.as<int64_t>();
+  ib.p = ob.p = nullptr;
+  m->mg_k = k, m->mg_steps = steps, m->mg_bytes = total * 2 * (long long)sizeof(double);
+  return QK_OK;
+}
+
 static int ensure_plan_uploaded(qk_ctx* c, qk_plan* p) {
   if (p->d_pairs && p->up_ctx == c) return QK_OK;
   if (p->d_pairs) {
@@ -1177,6 +1255,7 @@ extern "C" int qk_gram_values(qk_ctx* c, const qk_mps_set* xs, const qk_mps_set*
   a.values = values_dev, a.z = z_dev;
   a.scratch = c->scratch, a.x_plane = x_plane, a.t_plane = t_plane;
   a.xedge = a.yedge = nullptr, a.xedge_offs = a.yedge_offs = nullptr, a.edge_k = 0;
+  a.xmg = a.ymg = nullptr, a.xmg_offs = a.ymg_offs = nullptr, a.merge_steps = 0;
   a.counter = c->counter;
   a.nq = 1;  // kernels with XCD queues (site-fused, wave2) get the plan's queues below
   for (int s_ = 0; s_ <= QK_NQ_MAX; ++s_) a.qstart[s_] = plan->nq > 1 ? plan->qstart[s_] : (s_ == 0 ? 0 : np);
@@ -1246,6 +1325,13 @@ extern "C" int qk_gram_values(qk_ctx* c, const qk_mps_set* xs, const qk_mps_set*
         if (rc_e != QK_OK) return rc_e;
       }
       a.xedge = xs->d_edge, a.xedge_offs = xs->d_edge_offs, a.yedge = ys->d_edge, a.yedge_offs = ys->d_edge_offs, a.edge_k = plan->edge_k;
+    }
+    if (c->merge_sites && xs->n_sites - 2 * plan->edge_k >= 2) {  // the chain's sites contracted in twos: a workgroup picks per pair and step
+      for (const qk_mps_set* m : {xs, ys}) {
+        const int rc_m = ensure_merged(c, const_cast<qk_mps_set*>(m), plan->edge_k);
+        if (rc_m != QK_OK) return rc_m;
+      }
+      a.xmg = xs->d_mg, a.xmg_offs = xs->d_mg_offs, a.ymg = ys->d_mg, a.ymg_offs = ys->d_mg_offs, a.merge_steps = xs->mg_steps;
     }
     a.x_plane = (long long)xs->max_pad * ys->max_pad;  // complex elements per global X buffer (two per workgroup)
     HIP_TRY(hipEventRecord(c->ev0, c->stream));        // the conversion above is not part of the sweep

@@ -795,6 +795,7 @@ def test_edge_blocks_agree_with_the_plain_chain(built, monkeypatch, edge):
     z_ref = np.array([[R.mps_inner(x.tensors, y.tensors) for x in xs] for y in ys])
     K_ref = R.gram_from_mps([m.tensors for m in xs])
     out = {}
+    monkeypatch.setenv("QK_MERGE", "0")  # (merged steps have their own test, with and without edge blocks; here the byte count below is the edge blocks' alone)
     for mode in ("0", edge):
         monkeypatch.setenv("QK_EDGE", mode)
         with engine.context(0) as ctx, ctx.upload(xs) as dx, ctx.upload(ys) as dy:
@@ -805,3 +806,32 @@ def test_edge_blocks_agree_with_the_plain_chain(built, monkeypatch, edge):
         assert np.array_equal(out[mode][0], out[mode][0].T)
     assert np.abs(out[edge][0] - out["0"][0]).max() < 1e-13 and np.abs(out[edge][1] - out["0"][1]).max() < 1e-13
     assert out[edge][2] > out["0"][2]  # the edge blocks are counted in the set's device bytes
+
+
+@pytest.mark.parametrize("n,edge", [(26, "0"), (26, "4"), (27, "4"), (27, "0"), (30, "6"), (12, "4")])
+def test_merged_sites_agree_with_the_plain_chain(built, monkeypatch, n, edge):
+    """The chain walked in merged steps (QK_MERGE: two neighbouring sites contracted over their bond into one tensor of physical
+    dimension 4, a last single site when the chain is odd) against the plain walk and the oracle: with and without edge blocks,
+    chains of even and odd length, ragged states from one tile to environments larger than the LDS buffer, complex overlaps."""
+    import qml_cutensornet_amd as Q
+    from oracle import restatement as R
+    from qml_cutensornet_amd import engine
+
+    rng = np.random.default_rng(n + int(edge))
+    caps = (300, 150, 96, 60, 33, 17, 200)
+    xs = [Q.random_mps(n, [min(2 ** min(k, n - k), c) for k in range(n + 1)], rng) for c in caps]
+    ys = [Q.random_mps(n, _ragged_profile(rng, n, c), rng) for c in (120, 40, 70)]
+    z_ref = np.array([[R.mps_inner(x.tensors, y.tensors) for x in xs] for y in ys])
+    K_ref = R.gram_from_mps([m.tensors for m in xs])
+    monkeypatch.setenv("QK_EDGE", edge)
+    out = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("QK_MERGE", mode)
+        with engine.context(0) as ctx, ctx.upload(xs) as dx, ctx.upload(ys) as dy:
+            out[mode] = (ctx.gram(dx), ctx.overlaps(dx, dy), dx.info()["device_bytes"])
+            assert "fused" in ctx.stats()["kernel_name"]
+    for mode in out:
+        assert np.abs(out[mode][0] - K_ref).max() < TOL and np.abs(out[mode][1] - z_ref).max() < TOL
+        assert np.array_equal(out[mode][0], out[mode][0].T)
+    assert np.abs(out["1"][0] - out["0"][0]).max() < 1e-13 and np.abs(out["1"][1] - out["0"][1]).max() < 1e-13
+    assert out["1"][2] > out["0"][2]  # the merged image is counted in the set's device bytes

@@ -30,15 +30,17 @@ def main():
     from qml_cutensornet_amd import engine
     from qml_cutensornet_amd.gram import GramJob
 
-    ctx = engine.Context(0)
-    xset = ctx.upload(states)
+    if os.environ.get("QK_AB_LIB"):  # another build of the library (e.g. the previous commit's) on the same box
+        engine.LIB_PATH = os.path.abspath(os.environ["QK_AB_LIB"])
     ref = None
     for st in settings:
-        for k in ("QK_PLAN_XCD", "QK_PLAN_TILE", "QK_FUSED_SPLIT", "QK_PLAN_SPLIT", "QK_EDGE"):
+        for k in ("QK_PLAN_XCD", "QK_PLAN_TILE", "QK_FUSED_SPLIT", "QK_PLAN_SPLIT", "QK_EDGE", "QK_MERGE"):
             os.environ.pop(k, None)
         for kv in st:
             k, v = kv.split("=")
             os.environ[k] = v
+        ctx = engine.Context(0)  # (a context per setting: some switches are read when it is made)
+        xset = ctx.upload(states)
         job = GramJob(ctx, xset, None, 1, 0)
         K = job.run()
         ms, ms2, tf, tf2 = [], [], [], []
@@ -52,8 +54,8 @@ def main():
         err = float(np.abs(K - ref).max())
         print(f"{' '.join(st):32s} kernel {np.mean(ms):8.2f} ms (second launch {np.mean(ms2):7.2f}), tail {np.mean(tf):.4f} / {np.mean(tf2):.4f}, queues {s_['queues']}, edge sites {job.plan.edge_sites}, {s_['kernel_name']}; max |K - K_first| {err:.2e}", flush=True)
         job.close()
-    xset.close()
-    ctx.close()
+        xset.close()
+        ctx.close()
 
 
 if __name__ == "__main__":
