@@ -41,19 +41,30 @@ def main():
             os.environ[k] = v
         ctx = engine.Context(0)  # (a context per setting: some switches are read when it is made)
         xset = ctx.upload(states)
-        job = GramJob(ctx, xset, None, 1, 0)
-        K = job.run()
+        world = int(os.environ.get("QK_AB_WORLD", "1"))  # QK_AB_WORLD=8: rank 0's share of an 8-rank job (values only, no exchange)
+        if world > 1:
+            plan = engine.Plan(xset.dims, None, world, 0, 0, False)
+            vals = torch.zeros(max(1, plan.max_pairs_per_rank), dtype=torch.float64, device="cuda")
+            ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+            run = lambda: ctx.gram_values(xset, None, plan, vals.data_ptr())  # noqa: E731
+            run()
+            torch.cuda.synchronize()
+            K = vals.cpu().numpy()
+        else:
+            job = GramJob(ctx, xset, None, 1, 0)
+            plan, run = job.plan, job.enqueue
+            K = job.run()
         ms, ms2, tf, tf2 = [], [], [], []
         for _ in range(steps):
-            job.enqueue()
+            run()
             torch.cuda.synchronize()
             s_ = ctx.stats()
             ms.append(s_["kernel_ms"]), ms2.append(s_["second_ms"]), tf.append(s_["tail_frac"]), tf2.append(s_["second_tail_frac"])
         if ref is None:
             ref = K
         err = float(np.abs(K - ref).max())
-        print(f"{' '.join(st):32s} kernel {np.mean(ms):8.2f} ms (second launch {np.mean(ms2):7.2f}), tail {np.mean(tf):.4f} / {np.mean(tf2):.4f}, queues {s_['queues']}, edge sites {job.plan.edge_sites}, {s_['kernel_name']}; max |K - K_first| {err:.2e}", flush=True)
-        job.close()
+        print(f"{' '.join(st):32s} kernel {np.mean(ms):8.2f} ms (second launch {np.mean(ms2):7.2f}), tail {np.mean(tf):.4f} / {np.mean(tf2):.4f}, queues {s_['queues']}, edge sites {plan.edge_sites}, {s_['kernel_name']}; max |K - K_first| {err:.2e}", flush=True)
+        plan.close()
         xset.close()
         ctx.close()
 
