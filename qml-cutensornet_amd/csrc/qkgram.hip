@@ -202,8 +202,10 @@ static double fused_cost(int n, const int32_t* a, const int32_t* b) {
 // qkf_edge_suffix) instead of walking them: the k that minimises, over a sample of this rank's pairs, the matrix instructions of
 // the sweep plus a fixed cost per site walked (two barriers, set-up, load latencies: 375 instructions' worth = 2.5 us of a 12-wave
 // workgroup, measured on uniform small chains, tools/site_overhead.py).  A block product costs tiles(a_k) tiles(b_k) 2^k / 4 x 3
-// instructions x 1.5 (its tiles stream both blocks from L2: calibrated on the 60-qubit x 6-layer set, where k = 5 / 6 / 7 / 8 / 9
-// measured 98.3 / 97.6 / 96.2 / 95.5 / 98.0 % of the plain sweep); the chain's cost is fused_cost's.  QK_EDGE=0 disables, QK_EDGE=k forces.  This is a contraction order chosen on the
+// instructions x 2 (its tiles stream both blocks from L2).  Calibrated on the two headline sets with merged steps in the middle of
+// the chain: 60 qubits x 6 layers, k = 6 / 7 / 8 / 9 measured 403.8 / 393.8 / 396.2 / 401.8 ms (model, relative to k = 8: 1.008 /
+// 0.997 / 1 / 1.036); 40 qubits x 4 layers, k = 5 .. 9: 13.23 / 13.11 / 12.80 / 12.85 / 13.83 ms (model 1.054 / 1.021 / 0.995 / 1 /
+// 1.087).  Before the merged steps (every site of the middle walked singly) k = 8 was the minimum, at factor 1.5; the chain's cost is fused_cost's.  QK_EDGE=0 disables, QK_EDGE=k forces.  This is a contraction order chosen on the
 // host (north star; reference call site G:380): while the bonds still grow like 2^k, the ends of the two states are cheaper to
 // contract across their physical legs than along the chain.
 static int choose_edge_k(const int n_sites, const int32_t* x_dims, const int32_t* y_dims, const std::vector<int32_t>& pairs) {
@@ -233,7 +235,7 @@ static int choose_edge_k(const int n_sites, const int32_t* x_dims, const int32_t
     for (int k = 1; k <= KMAX && n_sites >= 2 * k + 2; ++k) {
       ends += site[(size_t)k - 1] + site[(size_t)(n_sites - k)];
       if (k < KMIN) continue;
-      const double blocks = 1.5 * 3.0 * ((1 << k) / 4) * (t16(a[k]) * t16(b[k]) + t16(a[n_sites - k]) * t16(b[n_sites - k])) + 2 * over;
+      const double blocks = 2.0 * 3.0 * ((1 << k) / 4) * (t16(a[k]) * t16(b[k]) + t16(a[n_sites - k]) * t16(b[n_sites - k])) + 2 * over;
       total[(size_t)k] += chain - ends + blocks;
     }
   }

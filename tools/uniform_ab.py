@@ -16,9 +16,11 @@ def main():
     caps = [int(c) for c in sys.argv[1].split(",")]
     settings = [s.split(",") for s in sys.argv[2:]]
     rng = np.random.default_rng(1)
-    n, ns = 60, 181
+    n = 60
     for cap in caps:
         prof = [min(2 ** min(k, n - k), cap) for k in range(n + 1)]
+        ns = 181 if cap <= 96 else 61  # (fewer states at large bonds: the host makes them)
+        print(f"cap {cap}: making {ns} states", flush=True)
         states = [Q.random_mps(n, prof, rng) for _ in range(ns)]
         ref = None
         for st in settings:
