@@ -112,8 +112,8 @@ def sweep_source_sha():
 
 def quoted_traffic(cfg_name, kernels):
     """HBM / fabric bytes per launch from the committed rocprofv3 --pmc summary of the same workload (PMC counters cannot be
-    read from inside this process): {kernel name: bytes}, the file, or (None, reason) when the summary is missing or was
-    taken on other sources."""
+    read from inside this process): {kernel name: (bytes, executed matrix flops or None)}, the file, or (None, reason) when the summary
+    is missing or was taken on other sources."""
     pmc_file = os.path.join(ROOT, "profiles", "r03", cfg_name, "pmc_summary.json")
     if not os.path.exists(pmc_file):
         return None, "no committed summary for this workload"
@@ -128,7 +128,7 @@ def quoted_traffic(cfg_name, kernels):
         ent = next((v for name, v in pmc.get("kernels", {}).items() if k and k in name), None)
         if ent is None or "traffic_bytes_per_launch" not in ent:
             return None, f"the summary has no entry for {k}"
-        out[k] = ent["traffic_bytes_per_launch"]
+        out[k] = (ent["traffic_bytes_per_launch"], ent.get("mfma_flops_executed"))  # (bytes, flops the matrix cores executed: SQ_INSTS_VALU_MFMA_MOPS_F64)
     return out, os.path.relpath(pmc_file, ROOT)
 
 
@@ -381,14 +381,19 @@ def main():
         bound = "mfma" if intensity >= ridge else "hbm"
         # HBM / fabric bytes per sweep: quoted from the committed rocprofv3 --pmc summary of the SAME workload -- only while that summary
         # was taken on the sources this run was built from (profiles/run_rocprof.sh records their digest)
+        executed = None
         traffic, traffic_src = None, "none (a reduced or non-default workload: no committed PMC summary describes it)"
         cfg_dir = args.config if (world == 1 and args.precision == "f64" and not args.points and args.seed == 5 and args.gamma == (0.1 if args.config == "cfg5" else 1.0)) else None
         if cfg_dir:
             per_kernel, traffic_src = quoted_traffic(cfg_dir, [ln["kernel"] for ln in launches])
             if per_kernel:
                 for ln in launches:
-                    ln["traffic_bytes"] = per_kernel[ln["kernel"]]
-                traffic = float(sum(per_kernel.values()))
+                    ln["traffic_bytes"], ex = per_kernel[ln["kernel"]]
+                    if ex:  # what the matrix cores executed (3M complex product, k-steps trimmed to the true bonds, edge blocks, merged steps)
+                        ln["executed_mfma_tflop"] = ex / 1e12
+                        ln["executed_over_algorithmic_4m"] = ex * 4.0 / 3.0 / (ln["algorithmic_tflop"] * 1e12) if ln["algorithmic_tflop"] > 0 else None
+                traffic = float(sum(b for b, _ in per_kernel.values()))
+                executed = sum(e for _, e in per_kernel.values() if e) if all(e for _, e in per_kernel.values()) else None
                 traffic_src = f"quoted: {traffic_src} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of these kernels on this workload, gfx950 FETCH_SIZE correction as calibrated in profiles/r03/fetch_calibration.txt; source digest {sweep_source_sha()} matches)"
             else:
                 traffic_src = f"none ({traffic_src})"
@@ -446,6 +451,10 @@ def main():
                 # the same flop count with every bond rounded up to the 16-wide MFMA tile (four-product form); the sweep kernels issue
                 # 3/4 of the K-trimmed part of it (3M complex product): see profiles/r03/<config>/pmc_summary.json
                 "padded_4m_tflop_per_sweep": my["padded_flops"] / 1e12,
+                # what the matrix cores executed per sweep (quoted with the traffic, same PMC summary): in four-product equivalents (x 4/3)
+                # over the algorithmic count = the padding the kernels really pay (the planner's figure above pads K as well, which they do not)
+                "executed_mfma_tflop_per_sweep": executed / 1e12 if executed else None,
+                "executed_over_algorithmic_4m": (executed * 4.0 / 3.0 / my["flops"]) if (executed and my["flops"] > 0) else None,
                 "work_queues": int(last["queues"]),
                 "edge_sites": int(job.plan.edge_sites),  # sites at either end of the chain taken from per-state edge blocks (contraction order chosen on the host)
                 "launches": launches,
