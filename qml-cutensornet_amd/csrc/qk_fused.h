@@ -289,13 +289,19 @@ __device__ __forceinline__ void qkf_step_table(const SweepArgs& g, const int xi,
     rec[3 * e] = (v4i){a, a2, b, b2};
     rec[3 * e + 1] = (v4i){xt[e], (yt[e] + 3) >> 2, W, small ? 1 : 0};
     rec[3 * e + 2] = (v4i){((1 << 20) + mt - 1) / mt, ps, next, 0};
-    m_off[2 * e] = (long long)A;
-    m_off[2 * e + 1] = (long long)B;
+    // (as element offsets from the sets' plain images, whatever buffer the tensor lives in: the kernels add them to their pointer
+    //  ARGUMENTS, which keeps the fragment loads global_load -- an address that comes out of the table as an integer makes them
+    //  flat_load, whose waits cover the LDS counter as well)
+    m_off[2 * e] = (long long)(((const char*)A - (const char*)xdata) / 16);
+    m_off[2 * e + 1] = (long long)(((const char*)B - (const char*)ydata) / 16);
   };
   auto plain = [&](const int e, const int next) __attribute__((always_inline)) {
     const int a = xd[e], a2 = xd[e + 1], b = yd[e], b2 = yd[e + 1];
     put(e, a, a2, b, b2, 1, next, is_small(a, a2, b, b2, 2), xdata + (g.xoffs[(long long)xi * ns + e] >> 1), ydata + (g.yoffs[(long long)yj * ns + e] >> 1));
   };
+#ifdef QKF_EXP_NOMERGE
+  { for (int e = tid; e < ns; e += NT) plain(e, e + 1); return; }
+#endif
   if (g.merge_steps == 0) {
     for (int e = tid; e < ns; e += NT) plain(e, e + 1);
     return;
@@ -327,6 +333,8 @@ __global__ __launch_bounds__(64 * NW, WPS) void qk_sweep_fused_kernel(const Swee
   extern __shared__ __attribute__((aligned(16))) double lds_raw[];
   lds_v2d* const XL = (lds_v2d*)lds_raw;  // (a C-style cast: the generic -> LDS address-space cast)
   long long* const slot = reinterpret_cast<long long*>(lds_raw + 2 * XCAP);
+  const v2d* const xdata = reinterpret_cast<const v2d*>(g.xdata);  // interleaved complex128 images
+  const v2d* const ydata = reinterpret_cast<const v2d*>(g.ydata);
   v2d* const G0 = reinterpret_cast<v2d*>(g.scratch) + (long long)blockIdx.x * 2 * g.x_plane;  // two global X buffers of x_plane complex
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -349,10 +357,14 @@ __global__ __launch_bounds__(64 * NW, WPS) void qk_sweep_fused_kernel(const Swee
     s.a = rfl(r0.x), s.a2 = rfl(r0.y), s.b = rfl(r0.z), s.b2 = rfl(r0.w);
     s.at = rfl(r1.x), s.nks = rfl(r1.y), s.W = rfl(r1.z), s.small = rfl(r1.w) != 0;
     s.inv = rfl(r2.x);
+#ifdef QKF_EXP_PD2
+    s.ps = 1, s.pd = 2, s.next = k + 1;
+#else
     s.ps = rfl(r2.y), s.pd = 1 << s.ps, s.next = rfl(r2.z);
+#endif
     s.mt = s.a / TILE, s.nt = s.b2 / TILE, s.nn = s.a2 / TILE;
-    s.Ak = reinterpret_cast<const v2d*>(ldl(m_off + 2 * k));      // [a][pd][a2]
-    s.Bk = reinterpret_cast<const v2d*>(ldl(m_off + 2 * k + 1));  // [b][pd][b2]
+    s.Ak = xdata + ldl(m_off + 2 * k);      // [a][pd][a2]
+    s.Bk = ydata + ldl(m_off + 2 * k + 1);  // [b][pd][b2]
     return s;
   };
   // the streams of item `it` of a strip starting at block s0 (it = 2 (tbl * mt + ta) + p)
@@ -631,6 +643,8 @@ __global__ __launch_bounds__(64 * NW, WPS) void qk_sweep_fused_dual_kernel(const
   extern __shared__ __attribute__((aligned(16))) double lds_raw[];
   lds_v2d* const XL = (lds_v2d*)lds_raw;
   long long* const slot = reinterpret_cast<long long*>(lds_raw + 2 * XCAP);
+  const v2d* const xdata = reinterpret_cast<const v2d*>(g.xdata);
+  const v2d* const ydata = reinterpret_cast<const v2d*>(g.ydata);
   v2d* const G0 = reinterpret_cast<v2d*>(g.scratch) + (long long)blockIdx.x * 2 * g.x_plane;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -652,10 +666,14 @@ __global__ __launch_bounds__(64 * NW, WPS) void qk_sweep_fused_dual_kernel(const
     s.a = rfl(r0.x), s.a2 = rfl(r0.y), s.b = rfl(r0.z), s.b2 = rfl(r0.w);
     s.at = rfl(r1.x), s.nks = rfl(r1.y), s.W = rfl(r1.z), s.small = rfl(r1.w) != 0;
     s.inv = rfl(r2.x);
+#ifdef QKF_EXP_PD2
+    s.ps = 1, s.pd = 2, s.next = k + 1;
+#else
     s.ps = rfl(r2.y), s.pd = 1 << s.ps, s.next = rfl(r2.z);
+#endif
     s.mt = s.a / TILE, s.nt = s.b2 / TILE, s.nn = s.a2 / TILE;
-    s.Ak = reinterpret_cast<const v2d*>(ldl(m_off + 2 * k));
-    s.Bk = reinterpret_cast<const v2d*>(ldl(m_off + 2 * k + 1));
+    s.Ak = xdata + ldl(m_off + 2 * k);
+    s.Bk = ydata + ldl(m_off + 2 * k + 1);
     return s;
   };
   // the streams of pair `v` of a strip starting at block s0 (v = 2 (tp * mt + ta) + p; column blocks s0 + 2 tp, + 1)
@@ -938,7 +956,6 @@ __global__ __launch_bounds__(64, 2) void qk_sweep_wave2_kernel(const SweepArgs g
       // (pinned to scalar registers: left alone, the compiler folds the two true-bond loads and the per-lane select below into
       //  ONE per-lane vector load -- and the s_waitcnt vmcnt(0) behind it drains the LDS-DMAs in flight at every site)
       const int fa = xd[f_k], fb = yd[f_k], fat = __builtin_amdgcn_readfirstlane(xt[f_k]), fbt = __builtin_amdgcn_readfirstlane(yt[f_k]);
-      const int fat2 = __builtin_amdgcn_readfirstlane(xt[f_k + 1]), fbt2 = __builtin_amdgcn_readfirstlane(yt[f_k + 1]);
       f_a2 = xd[f_k + 1], f_b2 = yd[f_k + 1];
       f_A = xdata + (xo[f_k] >> 1) * ES, f_B = ydata + (yo[f_k] >> 1) * ES;
       const int kb = fb >> 4, nn = f_a2 >> 4, mt = fa >> 4, nt = f_b2 >> 4, gpb = kb + nn;
@@ -948,23 +965,17 @@ __global__ __launch_bounds__(64, 2) void qk_sweep_wave2_kernel(const SweepArgs g
       const bool is_b = h < kb;
       const int off = is_b ? ((h * TILE) * 2 + pp) * f_b2 + tb * TILE : ((ta * TILE) * 2 + pp) * f_a2 + (h - kb) * TILE;
       const int cnt = is_b ? min(4, (fbt - h * TILE + 3) >> 2) : min(4, (fat - ta * TILE + 3) >> 2);
-      // columns of the group below the true bond, in fours (64 bytes of a row): 1..4
-      const int cv4 = is_b ? min(4, (fbt2 - tb * TILE + 3) >> 2) : min(4, (fat2 - (h - kb) * TILE + 3) >> 2);
-      desc = off | (cnt << 16) | ((is_b ? 1 : 0) << 20) | (cv4 << 21);
+      desc = off | (cnt << 16) | ((is_b ? 1 : 0) << 20);
       f_n = nt * mt * 2 * gpb, f_i = 0;
     };
     // fetch the next group: its k-steps below the true bond (the rows above are zero padding: a third of the image at bonds
     // around 20); the pieces above are asked for again at the address of the last one needed -- an L1 hit, no fabric bytes --
-    // so that every group is the same number of LDS-DMAs and the consumer's wait is a constant.  Of each row only the columns
-    // below the true bond, in fours (64 bytes), are asked for -- the lanes of the others sit the LDS-DMA out: at the bonds of
-    // 11..19 that fill the 100-qubit set, the 16-column padding of the rows is another fifth of the bytes.  Their places in the ring
-    // keep whatever was there: that reaches only the rows and columns of X' above the true bonds, which are cleared at the end
-    // of every site (below).
+    // so that every group is the same number of LDS-DMAs and the consumer's wait is a constant.
     auto issue = [&]() __attribute__((always_inline)) {
       if (f_k >= ns) return;
       const int d = __builtin_amdgcn_readlane(desc, f_i);
-      const int off = d & 0xffff, cnt = (d >> 16) & 7, cv = ((d >> 21) & 7) * 4;
-      const bool is_b = ((d >> 20) & 1) != 0;
+      const int off = d & 0xffff, cnt = (d >> 16) & 7;
+      const bool is_b = (d >> 20) != 0;
       const int ld = is_b ? f_b2 : f_a2;
       const char* const base = (is_b ? f_B : f_A) + (long)off * ES;
       if constexpr (F32) {
@@ -972,13 +983,11 @@ __global__ __launch_bounds__(64, 2) void qk_sweep_wave2_kernel(const SweepArgs g
         const char* const src = base + (((lane >> 3) * 2) * ld + (lane & 7) * 2) * ES;
         const int last = (cnt - 1) >> 1;
 #pragma unroll
-        for (int pc = 0; pc < 2; ++pc)
-          if ((lane & 7) * 2 < cv) __builtin_amdgcn_global_load_lds(src + (min(pc, last) * 16 * ld) * ES, (lds_ptr_t)(ring + f_slot * GROUP + pc * 64), 16, 0, 0);
+        for (int pc = 0; pc < 2; ++pc) __builtin_amdgcn_global_load_lds(src + (min(pc, last) * 16 * ld) * ES, (lds_ptr_t)(ring + f_slot * GROUP + pc * 64), 16, 0, 0);
       } else {
         const char* const src = base + ((q * 2) * ld + j) * ES;
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
-          if (j < cv) __builtin_amdgcn_global_load_lds(src + (min(i, cnt - 1) * 8 * ld) * ES, (lds_ptr_t)(ring + (f_slot * 4 + i) * 64), 16, 0, 0);
+        for (int i = 0; i < 4; ++i) __builtin_amdgcn_global_load_lds(src + (min(i, cnt - 1) * 8 * ld) * ES, (lds_ptr_t)(ring + (f_slot * 4 + i) * 64), 16, 0, 0);
       }
       f_slot = (f_slot == NG - 1) ? 0 : f_slot + 1;
       if (++f_i == f_n) {
@@ -1086,27 +1095,10 @@ __global__ __launch_bounds__(64, 2) void qk_sweep_wave2_kernel(const SweepArgs g
           for (int tn = 0; tn < 2; ++tn) XN[tb][tn].re = n1a[tn] + n2a[tn], XN[tb][tn].im = n3a[tn] - n1a[tn] + n2a[tn];
         }
       }
-      if constexpr (NG > 0) {
-        // X' above the true bonds (in fours: the columns in between were fetched, and are zero) holds what the skipped lanes of
-        // the LDS-DMAs left in the ring: cleared here, so that it meets nothing but cleared rows at the next site
-        const int am = (xt[k + 1] + 3) & ~3, bm = (yt[k + 1] + 3) & ~3;
 #pragma unroll
-        for (int u = 0; u < 2; ++u)
+      for (int u = 0; u < 2; ++u)
 #pragma unroll
-          for (int v = 0; v < 2; ++v) {
-            const bool col = v * TILE + j < am;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-              const bool keep = col && (u * TILE + 4 * i + q < bm);
-              XA[u][v].re[i] = keep ? XN[u][v].re[i] : 0.0, XA[u][v].im[i] = keep ? XN[u][v].im[i] : 0.0;
-            }
-          }
-      } else {
-#pragma unroll
-        for (int u = 0; u < 2; ++u)
-#pragma unroll
-          for (int v = 0; v < 2; ++v) XA[u][v] = XN[u][v];
-      }
+        for (int v = 0; v < 2; ++v) XA[u][v] = XN[u][v];
     }
     {
       // z = X_n[0][0] sits in lane 0; broadcast and stored by every lane (see qk_sweep_wave_kernel for why)

@@ -747,6 +747,11 @@ __global__ __launch_bounds__(256) void qk_merge_kernel(const double* __restrict_
   }
 }
 
+#ifdef QK_LAB
+__global__ void qk_lab_fold_kernel(const int64_t* __restrict__ src, int64_t* __restrict__ dst, const long long n, const long long win) {
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) dst[i] = (src[i] % win) & ~1ll;
+}
+#endif
 // self-test: C[16x16] = sum_{k<16} P[k][m] * Q[k][n] with the fragment maps used above
 __global__ void qk_selftest_f32_kernel(const float* __restrict__ P, const float* __restrict__ Q, float* __restrict__ C) {
   const int lane = threadIdx.x & 63, j = lane & 15, q = lane >> 4;
@@ -1335,6 +1340,22 @@ extern "C" int qk_gram_values(qk_ctx* c, const qk_mps_set* xs, const qk_mps_set*
       }
       a.xmg = xs->d_mg, a.xmg_offs = xs->d_mg_offs, a.ymg = ys->d_mg, a.ymg_offs = ys->d_mg_offs, a.merge_steps = xs->mg_steps;
     }
+#ifdef QK_LAB  // TIMING EXPERIMENT (wrong results): every tensor read from the first MiB of its image -- what would perfect L2 hits buy?
+    if (const char* v = std::getenv("QK_DEBUG_ALIAS")) {
+      const long long win = std::atoll(v);  // window in doubles (e.g. 131072 = 1 MiB)
+      if (win > 0) {
+        auto fold = [&](const int64_t* src, const long long n) -> const int64_t* {
+          int64_t* dst = nullptr;
+          if (hipMalloc(&dst, (size_t)n * sizeof(int64_t)) != hipSuccess) return src;  // (leaked: experiment)
+          qk_lab_fold_kernel<<<dim3(256), dim3(256), 0, c->stream>>>(src, dst, n, win);
+          return dst;
+        };
+        a.xoffs = fold(a.xoffs, (long long)xs->n_states * xs->n_sites), a.yoffs = fold(a.yoffs, (long long)ys->n_states * ys->n_sites);
+        if (a.merge_steps > 0)
+          a.xmg_offs = fold(a.xmg_offs, (long long)xs->n_states * xs->mg_steps), a.ymg_offs = fold(a.ymg_offs, (long long)ys->n_states * ys->mg_steps);
+      }
+    }
+#endif
     a.x_plane = (long long)xs->max_pad * ys->max_pad;  // complex elements per global X buffer (two per workgroup)
     HIP_TRY(hipEventRecord(c->ev0, c->stream));        // the conversion above is not part of the sweep
     a.nq = plan->nq, c->last.queues = plan->nq > 1 ? 8 : 1, c->tail_pending = true;

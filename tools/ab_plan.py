@@ -17,8 +17,12 @@ def main():
     steps = int(sys.argv[2]) if len(sys.argv) > 2 else 3
     settings = [s.split(",") for s in (sys.argv[3:] or ["QK_PLAN_XCD=0", "QK_PLAN_TILE=8", "QK_PLAN_TILE=4", "QK_PLAN_TILE=16", "QK_PLAN_XCD=0"])]
     import __graft_entry__ as graft
+    from qml_cutensornet_amd import engine
 
+    if os.environ.get("QK_AB_LIB"):  # another build of the library (e.g. the previous commit's) on the same box: BEFORE build() loads the shipped one
+        engine.LIB_PATH = os.path.abspath(os.environ["QK_AB_LIB"])
     graft.build()
+    print(f"library: {engine.LIB_PATH}", flush=True)
     from qml_cutensornet_amd.builder_pool import default_workers
 
     n, reps, d, npts = bench.CONFIGS[cfg]
@@ -27,14 +31,11 @@ def main():
     print(f"states: {binfo}", flush=True)
     import torch
 
-    from qml_cutensornet_amd import engine
     from qml_cutensornet_amd.gram import GramJob
 
-    if os.environ.get("QK_AB_LIB"):  # another build of the library (e.g. the previous commit's) on the same box
-        engine.LIB_PATH = os.path.abspath(os.environ["QK_AB_LIB"])
     ref = None
     for st in settings:
-        for k in ("QK_PLAN_XCD", "QK_PLAN_TILE", "QK_FUSED_SPLIT", "QK_PLAN_SPLIT", "QK_EDGE", "QK_MERGE"):
+        for k in ("QK_PLAN_XCD", "QK_PLAN_TILE", "QK_FUSED_SPLIT", "QK_PLAN_SPLIT", "QK_EDGE", "QK_MERGE", "QK_DEBUG_ALIAS"):
             os.environ.pop(k, None)
         for kv in st:
             k, v = kv.split("=")
