@@ -167,8 +167,15 @@ static constexpr int QKF_XCAP_ONE = QKF_XCAP_ONE_V, QKF_XCAP_TWO = 4608;  // ele
 #define QKF_DUAL_WPS 3
 #endif
 #define QKF_KERNEL_DUAL qk_sweep_fused_dual_kernel<QKF_DUAL_NW, QKF_XCAP_ONE, QKF_DUAL_WPS>
-static void pair_work(int n, const int32_t* a, const int32_t* b, double* flops, double* padded, double* bytes, double* fit_two = nullptr) {
-  double f = 0, fp = 0, by = 0, ft = 0;
+// The narrow site size of the pair classes (QK_PLAN_FIT, elements of X): when a set holds a substantial share of LARGE pairs, only
+// pairs whose work sits in sites of at most this many elements go to the two-workgroup shape -- the 12-wave dual shape is the
+// better one from about 4 x 4 tiles per site on (uniform chains: bond 48 39.8 against 42.4 ms for the two-workgroup shape, bond 64
+// 99.8 against 86.6 ms).  60 qubits x 6 layers, whole sweep: 4608 (every site that fits the smaller buffer) 377.0 ms, 3584 365.9,
+// 3072 365.6, 2560 and below (one launch of the dual shape) 368.1.  A set without large pairs (40 qubits x 4 layers) stays on the
+// two-workgroup shape as a whole: 12.65 ms against 13.1-13.2 when split at the narrow size.
+static double g_plan_fit = 3072;  // (set by qk_plan_create)
+static void pair_work(int n, const int32_t* a, const int32_t* b, double* flops, double* padded, double* bytes, double* fit_two = nullptr, double* fit_narrow = nullptr) {
+  double f = 0, fp = 0, by = 0, ft = 0, fn = 0;
   for (int k = 0; k < n; ++k) {
     const double a0 = a[k], a1 = a[k + 1], b0 = b[k], b1 = b[k + 1];
     const double f1 = a0 * b0 * 2 * b1 + 2 * a0 * a1 * b1;
@@ -177,9 +184,11 @@ static void pair_work(int n, const int32_t* a, const int32_t* b, double* flops, 
     const double A0 = pad16(a[k]), A1 = pad16(a[k + 1]), B0 = pad16(b[k]), B1 = pad16(b[k + 1]);
     fp += 8 * (A0 * B0 * 2 * B1 + 2 * A0 * A1 * B1);
     if (A0 * B0 <= QKF_XCAP_TWO && A1 * B1 <= QKF_XCAP_TWO) ft += 8 * (A0 * B0 * 2 * B1 + 2 * A0 * A1 * B1);  // X and X' of this site fit the smaller buffer
+    if (A0 * B0 <= g_plan_fit && A1 * B1 <= g_plan_fit) fn += 8 * (A0 * B0 * 2 * B1 + 2 * A0 * A1 * B1);      // ... with room to spare (see g_plan_fit)
     by += 16.0 * 2 * (a0 * a1 + b0 * b1);
   }
   if (fit_two) *fit_two = ft;
+  if (fit_narrow) *fit_narrow = fn;
   *flops = f;
   *padded = fp;
   *bytes = by + 8;
@@ -276,7 +285,7 @@ static void plan_tiled(qk_plan* p, const int n_sites, const int nx, const int32_
   const std::vector<int> ox = order_of(nx, x_dims), oy = sym ? ox : order_of(ny, y_dims);
   struct Item {
     int32_t i, j;
-    double f, fp, by, ft;
+    double f, fp, by, ft, fn;
   };
   struct Tile {
     int64_t start, count;
@@ -297,7 +306,7 @@ static void plan_tiled(qk_plan* p, const int n_sites, const int nx, const int32_
           if (orient && xi != yj && fused_cost(n_sites, x_dims + (int64_t)yj * stride, y_dims + (int64_t)xi * stride) < fused_cost(n_sites, x_dims + (int64_t)xi * stride, y_dims + (int64_t)yj * stride))
             std::swap(xi, yj);
           Item it{xi, yj, 0, 0, 0, 0};
-          pair_work(n_sites, x_dims + (int64_t)xi * stride, y_dims + (int64_t)yj * stride, &it.f, &it.fp, &it.by, &it.ft);
+          pair_work(n_sites, x_dims + (int64_t)xi * stride, y_dims + (int64_t)yj * stride, &it.f, &it.fp, &it.by, &it.ft, &it.fn);
           items.push_back(it);
           t.cost += it.fp;
         }
@@ -369,7 +378,11 @@ static void plan_tiled(qk_plan* p, const int n_sites, const int nx, const int32_
   const bool mixed = any_large && n_small_pairs >= std::max<int64_t>(64, n_mine / 50) && n_small_pairs < n_mine && !std::getenv("QK_PLAN_NO_MIXED");
   p->second_wave2 = mixed;
   const bool two_classes = mixed || !(small_work < 0.05 * padded || small_work > 0.95 * padded);
-  auto cls_of = [&](const Item& it) { return mixed ? (small_pair(it) ? 1 : 0) : ((two_classes && it.fp > 0 && it.ft >= split * it.fp) ? 1 : 0); };
+  // with a quarter or more of the work in large pairs the second class is cut at the narrow site size (g_plan_fit)
+  const bool narrow = !mixed && two_classes && small_work < 0.75 * padded;
+  auto cls_of = [&](const Item& it) {
+    return mixed ? (small_pair(it) ? 1 : 0) : ((two_classes && it.fp > 0 && (narrow ? it.fn : it.ft) >= split * it.fp) ? 1 : 0);
+  };
   p->pairs.clear(), p->groups.clear();
   p->second = qk_stats{};
   p->nq = QK_NQ_MAX;
@@ -427,6 +440,10 @@ extern "C" int qk_plan_create(int32_t n_sites, int32_t nx, const int32_t* x_dims
   } else if (!y_dims || ny <= 0)
     return fail(QK_EINVAL, "qk_plan_create: y_dims required unless symmetric");
   if (world_size <= 0 || rank < 0 || rank >= world_size) return fail(QK_EINVAL, "qk_plan_create: bad rank %d/%d", rank, world_size);
+  {
+    const char* e = std::getenv("QK_PLAN_FIT");
+    g_plan_fit = e ? std::atof(e) : 3072.0;
+  }
   const int block_arg = block;
   if (block <= 0) block = std::max(nx, ny);  // flat list (QK_PLAN_XCD=0): the whole pair list in cost order
   qk_plan* p = new (std::nothrow) qk_plan;

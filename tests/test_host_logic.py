@@ -252,35 +252,41 @@ def test_oriented_plan_lists_each_pair_once_in_the_cheaper_order(built):
 
 
 def test_plan_lists_the_pairs_of_small_sites_last(built, monkeypatch):
-    """Sets of very different entanglement: the pairs with >= QK_PLAN_SPLIT of their padded work in sites whose X and X' fit the
-    site-fused kernel's smaller LDS buffer (4608 elements) form the second run of the plan; each run in decreasing cost."""
+    """Sets of very different entanglement: the pairs with >= QK_PLAN_SPLIT of their padded work in SMALL sites form the second run
+    of the plan.  Small = X and X' fit the site-fused kernel's smaller LDS buffer (4608 elements) -- or, when a quarter or more of the
+    set's work lies in pairs that do not qualify by that measure, the narrow site size QK_PLAN_FIT (3072): only pairs of really small
+    sites leave the 12-wave shape then."""
     from qml_cutensornet_amd import engine
 
     rng = np.random.default_rng(11)
     nx, n = 30, 12
-    xd = np.ones((nx, n + 1), dtype=np.int32)
-    xd[:24, 1:-1] = rng.integers(40, 65, size=(24, n - 1))   # small states
-    xd[24:, 1:-1] = rng.integers(90, 130, size=(6, n - 1))   # large states
     p16 = lambda v: -(-v // 16) * 16
 
-    def fit_share(a, b):
+    def fit_share(a, b, fit):
         w = ft = 0.0
         for k in range(n):
             A0, A1, B0, B1 = p16(a[k]), p16(a[k + 1]), p16(b[k]), p16(b[k + 1])
             c = A0 * B0 * 2 * B1 + 2 * A0 * A1 * B1
             w += c
-            ft += c if (A0 * B0 <= 4608 and A1 * B1 <= 4608) else 0.0
-        return ft / w
+            ft += c if (A0 * B0 <= fit and A1 * B1 <= fit) else 0.0
+        return ft / w, w
 
-    for split in (0.75, 0.5):
-        monkeypatch.setenv("QK_PLAN_SPLIT", str(split))
-        p = engine.Plan(xd)
-        pr, first = p.pairs(), p.first_run
-        assert 0 < first < len(pr) == nx * (nx + 1) // 2
-        assert len({tuple(sorted(t)) for t in pr.tolist()}) == len(pr)
-        shares = np.array([fit_share(xd[i], xd[j]) for i, j in pr.tolist()])
-        assert (shares[:first] < split).all() and (shares[first:] >= split).all()
-        p.close()
+    for n_large, narrow in ((6, True), (1, False)):  # many large states: the narrow measure; a single one: the buffer size
+        xd = np.ones((nx, n + 1), dtype=np.int32)
+        xd[: nx - n_large, 1:-1] = rng.integers(40, 65, size=(nx - n_large, n - 1))  # small states
+        xd[nx - n_large :, 1:-1] = rng.integers(90, 130, size=(n_large, n - 1))      # large states
+        for split in (0.75, 0.5):
+            monkeypatch.setenv("QK_PLAN_SPLIT", str(split))
+            p = engine.Plan(xd)
+            pr, first = p.pairs(), p.first_run
+            assert 0 < first < len(pr) == nx * (nx + 1) // 2
+            assert len({tuple(sorted(t)) for t in pr.tolist()}) == len(pr)
+            wide = [fit_share(xd[i], xd[j], 4608) for i, j in pr.tolist()]
+            large_work = sum(w for sh, w in wide if sh < split) / sum(w for _, w in wide)
+            assert (large_work >= 0.25) == narrow
+            shares = np.array([fit_share(xd[i], xd[j], 3072 if narrow else 4608)[0] for i, j in pr.tolist()])
+            assert (shares[:first] < split).all() and (shares[first:] >= split).all()
+            p.close()
     monkeypatch.setenv("QK_PLAN_SPLIT", "2")  # nothing qualifies: one run
     p = engine.Plan(xd)
     assert p.first_run == p.num_pairs
