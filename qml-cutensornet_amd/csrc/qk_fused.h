@@ -20,12 +20,16 @@
 //     stream never drains: the last group of a tile loads the first group of the wave's next tile, of its first
 //     phase-2 group, or of its first tile of the NEXT site, across the barriers.  No staging ring, no per-K-tile
 //     barrier: a wave runs its items autonomously and the workgroup meets at two or three barriers per site.  The
-//     fragments that several items share are re-read through L1/L2, never through the fabric;
+//     fragments that several items share are re-read through the caches (which catch a fifth to a quarter of them: the rest comes
+//     back over the fabric -- DESIGN.md, cache counters);
 //   * K is walked in units of 4 up to the TRUE bond; the complex product is the 3M form of the ring kernel;
 //   * sites too large for the LDS run in STRIPS: X is read from a per-workgroup global buffer (A-operand fragments
 //     loaded like the site tensors), X' is accumulated a block of b' rows at a time (as many as fit the LDS), items in
 //     rounds of (waves x slots), and written to the other global buffer;
-//   * per-site control is a 48-byte record per site, computed by all threads at pair set-up.
+//   * the chain is walked in STEPS: the first and last k sites of both states come as edge blocks (one product each), a step in
+//     between is one site or two neighbouring sites contracted into one tensor of physical dimension 4 (merged image of the set),
+//     whichever costs less for the pair at hand; per-step control is a 48-byte record, the step table of the pair, built by all
+//     threads at pair set-up (qkf_step_table).
 // Two launch shapes (chosen per launch -- or per run of pairs of a split plan -- in qkgram.hip): one 12-wave workgroup per CU
 // (three waves per SIMD at 168 VGPRs, two tiles per wave) with an 8192-element X buffer -- by default in its DUAL form
 // (qk_sweep_fused_dual_kernel below: the two tiles of a wave share the rows of X and of A, so every A and X fragment feeds
@@ -299,9 +303,6 @@ __device__ __forceinline__ void qkf_step_table(const SweepArgs& g, const int xi,
     const int a = xd[e], a2 = xd[e + 1], b = yd[e], b2 = yd[e + 1];
     put(e, a, a2, b, b2, 1, next, is_small(a, a2, b, b2, 2), xdata + (g.xoffs[(long long)xi * ns + e] >> 1), ydata + (g.yoffs[(long long)yj * ns + e] >> 1));
   };
-#ifdef QKF_EXP_NOMERGE
-  { for (int e = tid; e < ns; e += NT) plain(e, e + 1); return; }
-#endif
   if (g.merge_steps == 0) {
     for (int e = tid; e < ns; e += NT) plain(e, e + 1);
     return;
@@ -357,11 +358,7 @@ __global__ __launch_bounds__(64 * NW, WPS) void qk_sweep_fused_kernel(const Swee
     s.a = rfl(r0.x), s.a2 = rfl(r0.y), s.b = rfl(r0.z), s.b2 = rfl(r0.w);
     s.at = rfl(r1.x), s.nks = rfl(r1.y), s.W = rfl(r1.z), s.small = rfl(r1.w) != 0;
     s.inv = rfl(r2.x);
-#ifdef QKF_EXP_PD2
-    s.ps = 1, s.pd = 2, s.next = k + 1;
-#else
     s.ps = rfl(r2.y), s.pd = 1 << s.ps, s.next = rfl(r2.z);
-#endif
     s.mt = s.a / TILE, s.nt = s.b2 / TILE, s.nn = s.a2 / TILE;
     s.Ak = xdata + ldl(m_off + 2 * k);      // [a][pd][a2]
     s.Bk = ydata + ldl(m_off + 2 * k + 1);  // [b][pd][b2]
@@ -666,11 +663,7 @@ __global__ __launch_bounds__(64 * NW, WPS) void qk_sweep_fused_dual_kernel(const
     s.a = rfl(r0.x), s.a2 = rfl(r0.y), s.b = rfl(r0.z), s.b2 = rfl(r0.w);
     s.at = rfl(r1.x), s.nks = rfl(r1.y), s.W = rfl(r1.z), s.small = rfl(r1.w) != 0;
     s.inv = rfl(r2.x);
-#ifdef QKF_EXP_PD2
-    s.ps = 1, s.pd = 2, s.next = k + 1;
-#else
     s.ps = rfl(r2.y), s.pd = 1 << s.ps, s.next = rfl(r2.z);
-#endif
     s.mt = s.a / TILE, s.nt = s.b2 / TILE, s.nn = s.a2 / TILE;
     s.Ak = xdata + ldl(m_off + 2 * k);
     s.Bk = ydata + ldl(m_off + 2 * k + 1);
