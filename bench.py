@@ -222,6 +222,9 @@ def main():
     ap.add_argument("--seed", type=int, default=5)
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU-baseline budget (0 = skip)")
     ap.add_argument("--workers", type=int, default=0, help="host processes for MPS building (0 = all cores / ranks)")
+    ap.add_argument("--max-bond", type=int, default=0,
+                    help="bond cap chi (the `chi` of pytket-cutensornet's Config, ref gpu_backend/kernel_state_ansatz.py:141-144; 0 = none, like the reference): "
+                    "the states are then built by the DEVICE builder, truncating at chi -- what makes cfg5 runnable beyond gamma = 0.1")
     ap.add_argument("--precision", default="f64", choices=["f64", "f32"],
                     help="f64 = the reference's precision and the headline metric; f32 = the complex64 sweep (SURVEY 8f N4), a supplementary line")
     args = ap.parse_args()
@@ -246,9 +249,17 @@ def main():
         npts = args.points
     workers = args.workers or max(1, default_workers() // world)
     log(rank, f"{args.config}: {n} qubits x {reps} layers, d={d}, gamma={args.gamma}, {npts} points; {world} GPU(s); {workers} builder procs/rank")
-    states, binfo = build_or_load_states(args.config, n, reps, d, args.gamma, npts, args.seed, rank, world, workers)
-    chi_max = np.array([m.max_bond() for m in states])
-    log(rank, f"states ready: built {binfo['built_here']} here in {binfo['build_wall_s']:.1f}s ({binfo['cpu_s_per_state']:.2f} cpu-s/state); max bond mean {chi_max.mean():.1f} max {chi_max.max()}")
+    if args.max_bond:  # capped bonds: the device builder makes the states once the GPU is up (every rank its own copy)
+        import qml_cutensornet_amd as Q
+        from qml_cutensornet_amd.data import synthetic_features
+
+        states = None
+        binfo = {"built_here": 0, "build_wall_s": 0.0, "cpu_s_per_state": float("nan"), "X": synthetic_features(npts, n, args.seed),
+                 "ansatz": Q.KernelStateAnsatz(n, reps, args.gamma, Q.entanglement_graph(n, d))}
+    else:
+        states, binfo = build_or_load_states(args.config, n, reps, d, args.gamma, npts, args.seed, rank, world, workers)
+        chi_max = np.array([m.max_bond() for m in states])
+        log(rank, f"states ready: built {binfo['built_here']} here in {binfo['build_wall_s']:.1f}s ({binfo['cpu_s_per_state']:.2f} cpu-s/state); max bond mean {chi_max.mean():.1f} max {chi_max.max()}")
 
     # ---- phase 1: GPU --------------------------------------------------------------------------------
     import torch
@@ -278,6 +289,18 @@ def main():
 
     ctx = engine.Context(local_rank)
     ctx.selftest()
+    capped_build = None
+    if args.max_bond:
+        circs = [binfo["ansatz"].circuit_for_data(x) for x in binfo["X"]]
+        t0 = time.perf_counter()
+        states, dinfo = ctx.build_mps(circs, max_bond=args.max_bond, truncate=True)
+        ctx.trim()
+        fids = np.array([m.fidelity for m in states])
+        chi_max = np.array([m.max_bond() for m in states])
+        capped_build = {"device_kernel_s": dinfo["kernel_ms"] / 1e3, "device_wall_s_with_download": time.perf_counter() - t0, "max_bond_cap": args.max_bond, "truncated_at_cap": True,
+                        "fidelity_median": float(np.median(fids)), "fidelity_min": float(fids.min())}
+        log(rank, f"device MPS builder, bonds cut at {args.max_bond}: {npts} states in {capped_build['device_kernel_s']:.2f} s; max bond mean {chi_max.mean():.1f} max {chi_max.max()}; "
+                  f"truncation fidelity median {capped_build['fidelity_median']:.3g}")
     t0 = time.perf_counter()
     xset = ctx.upload(states)
     upload_s = time.perf_counter() - t0
@@ -293,7 +316,7 @@ def main():
         info = xset.info()
     # the device MPS builder on the same circuits (rank 0, one GPU; QK_BENCH_DEVICE_BUILD=0 skips it): reported beside the host pool
     dev_build, K_dev = None, None
-    if world == 1 and args.precision == "f64" and os.environ.get("QK_BENCH_DEVICE_BUILD", "1") != "0":
+    if world == 1 and args.precision == "f64" and not args.max_bond and os.environ.get("QK_BENCH_DEVICE_BUILD", "1") != "0":
         dev_build, K_dev = device_build_leg(ctx, binfo["ansatz"], binfo["X"], states, lambda t: log(rank, t))
         if "error" not in dev_build:
             log(rank, f"device MPS builder: {npts} states in {dev_build['device_kernel_s']:.2f} s (wall {dev_build['device_wall_s']:.2f} s); host pool: {binfo['cpu_s_per_state'] * npts / workers:.1f} s on {workers} workers")
@@ -383,7 +406,7 @@ def main():
         # was taken on the sources this run was built from (profiles/run_rocprof.sh records their digest)
         executed = None
         traffic, traffic_src = None, "none (a reduced or non-default workload: no committed PMC summary describes it)"
-        cfg_dir = args.config if (world == 1 and args.precision == "f64" and not args.points and args.seed == 5 and args.gamma == (0.1 if args.config == "cfg5" else 1.0)) else None
+        cfg_dir = args.config if (world == 1 and args.precision == "f64" and not args.max_bond and not args.points and args.seed == 5 and args.gamma == (0.1 if args.config == "cfg5" else 1.0)) else None
         if cfg_dir:
             per_kernel, traffic_src = quoted_traffic(cfg_dir, [ln["kernel"] for ln in launches])
             if per_kernel:
@@ -409,9 +432,9 @@ def main():
             "scaling": "strong",
             "vs_baseline": None,
             "dtype": "f64 (complex128)" if args.precision == "f64" else "f32 (complex64)",
-            "data": "synthetic features (normal -> standardise -> MinMax[0,2], seed %d); real ansatz MPS built on the host" % args.seed,
+            "data": "synthetic features (normal -> standardise -> MinMax[0,2], seed %d); real ansatz MPS built %s" % (args.seed, f"on the device, bonds cut at {args.max_bond}" if args.max_bond else "on the host"),
             "config": {
-                "workload": f"{args.config}: {n} qubits x {reps} layers, d={d}, gamma={args.gamma}, truncation 1e-16, {npts}x{npts} symmetric training Gram",
+                "workload": f"{args.config}: {n} qubits x {reps} layers, d={d}, gamma={args.gamma}, truncation 1e-16{f', bond cap {args.max_bond}' if args.max_bond else ''}, {npts}x{npts} symmetric training Gram",
                 "unique_pairs": int(job.plan.total_pairs),
                 "overlaps_per_s": job.plan.total_pairs / (ms_per_step * 1e-3),
                 "parallelism": f"states sorted by weight, Gram cut into 8 x 8 tiles of pairs, tiles dealt by cost to {world} rank(s) and, per rank, to 8 per-XCD work queues; one {'RCCL' if backend == 'nccl' else backend} all-gather of packed values",
@@ -419,7 +442,7 @@ def main():
                 "max_bond_max": int(chi_max.max()),
                 "mps_gib": info["device_bytes"] / 2**30,
                 # the input producer (not part of the timed step): host pool (cpu-s per state, measured when built here) and the device builder
-                "mps_build": {"host_cpu_s_per_state": binfo["cpu_s_per_state"], "host_workers": workers, "host_pool_s": binfo["cpu_s_per_state"] * npts / workers,
+                "mps_build": capped_build if capped_build else {"host_cpu_s_per_state": binfo["cpu_s_per_state"], "host_workers": workers, "host_pool_s": binfo["cpu_s_per_state"] * npts / workers,
                               "host_pool_wall_s_this_run": binfo["build_wall_s"] if binfo["built_here"] == npts else None, **(dev_build or {})},
                 "diag_err": diag_err,
                 "sym_err": sym_err,
