@@ -98,6 +98,7 @@ struct qk_plan {
   int edge_k = 0;             // sites at either end of the chain that the fused sweep takes from the sets' edge blocks (0: none)
   bool second_wave2 = false;  // the second run holds the pairs of two states whose bonds are all <= 32: swept by the one-wave kernel (mixed sets)
   double fit_two = 1.0;  // share of this rank's padded work in sites whose X and X' fit the fused sweep's smaller LDS buffer
+  double fit_narrow = 1.0;  // ... in sites of at most the narrow size (QK_PLAN_FIT: where the two-workgroup shape still beats the 12-wave dual one)
   // lazily uploaded copy
   qk_ctx* up_ctx = nullptr;
   int32_t* d_pairs = nullptr;

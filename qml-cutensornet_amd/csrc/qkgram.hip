@@ -353,11 +353,11 @@ static void plan_tiled(qk_plan* p, const int n_sites, const int nx, const int32_
   // classes of this rank's pairs (see qk_plan_create): class 1 = nearly all of the work fits the fused sweep's smaller LDS buffer
   double split = 0.75;
   if (const char* e = std::getenv("QK_PLAN_SPLIT")) split = std::atof(e);
-  double flops = 0, padded = 0, bytes = 0, fit_two = 0, small_work = 0;
+  double flops = 0, padded = 0, bytes = 0, fit_two = 0, fit_narrow = 0, small_work = 0;
   for (const int t : mine)
     for (int64_t q = tiles[(size_t)t].start; q < tiles[(size_t)t].start + tiles[(size_t)t].count; ++q) {
       const Item& it = items[(size_t)q];
-      flops += it.f, padded += it.fp, bytes += it.by, fit_two += it.ft;
+      flops += it.f, padded += it.fp, bytes += it.by, fit_two += it.ft, fit_narrow += it.fn;
       if (it.fp > 0 && it.ft >= split * it.fp) small_work += it.fp;
     }
   // A MIXED set -- some states with every bond <= 32 next to larger ones -- keeps its small-small pairs on the one-wave sweep
@@ -426,6 +426,7 @@ static void plan_tiled(qk_plan* p, const int n_sites, const int nx, const int32_
   p->stats.pairs = np;
   p->stats.flops = flops, p->stats.padded_flops = padded, p->stats.bytes = bytes;
   p->fit_two = padded > 0 ? fit_two / padded : 1.0;
+  p->fit_narrow = padded > 0 ? fit_narrow / padded : 1.0;
   p->edge_k = choose_edge_k(n_sites, x_dims, y_dims, p->pairs);
 }
 
@@ -530,7 +531,7 @@ extern "C" int qk_plan_create(int32_t n_sites, int32_t nx, const int32_t* x_dims
   int64_t t = 0;  // running index in the global order
   std::vector<int64_t> per_rank(world_size, 0);
   std::vector<int32_t> tile_of;  // locality tile of each pair of this rank
-  double flops = 0, padded = 0, bytes = 0, fit_two = 0;
+  double flops = 0, padded = 0, bytes = 0, fit_two = 0, fit_narrow = 0;
   const int nbx = (nx + block - 1) / block, nby = (ny + block - 1) / block;
   for (int bj = 0; bj < nby; ++bj)
     for (int bi = 0; bi < nbx; ++bi) {
@@ -557,9 +558,9 @@ extern "C" int qk_plan_create(int32_t n_sites, int32_t nx, const int32_t* x_dims
           p->pairs.push_back(it.i);
           p->pairs.push_back(it.j);
           tile_of.push_back(bj * nbx + bi);
-          double f, fp, by, ft;
-          pair_work(n_sites, x_dims + (int64_t)it.i * stride, y_dims + (int64_t)it.j * stride, &f, &fp, &by, &ft);
-          flops += f, padded += fp, bytes += by, fit_two += ft;
+          double f, fp, by, ft, fn;
+          pair_work(n_sites, x_dims + (int64_t)it.i * stride, y_dims + (int64_t)it.j * stride, &f, &fp, &by, &ft, &fn);
+          flops += f, padded += fp, bytes += by, fit_two += ft, fit_narrow += fn;
         }
         ++t;
       }
@@ -631,6 +632,7 @@ extern "C" int qk_plan_create(int32_t n_sites, int32_t nx, const int32_t* x_dims
   p->stats.pairs = (int64_t)p->pairs.size() / 2;
   p->stats.flops = flops, p->stats.padded_flops = padded, p->stats.bytes = bytes;
   p->fit_two = padded > 0 ? fit_two / padded : 1.0;
+  p->fit_narrow = padded > 0 ? fit_narrow / padded : 1.0;
   p->nq = 1;  // the flat list: one queue per launch
   p->edge_k = choose_edge_k(n_sites, x_dims, y_dims, p->pairs);
   *out = p;
@@ -1255,7 +1257,10 @@ extern "C" int qk_gram_values(qk_ctx* c, const qk_mps_set* xs, const qk_mps_set*
   const bool two_runs = fused && can_one && can_two && c->fused_wgs == 0 && c->fused_split && !plan->second_wave2 && plan->n_first > 0 && plan->n_first < np;
   // a mixed set: the plan's second run holds the pairs of two small states (every bond <= 32) for the one-wave sweep
   const bool mixed = fused && plan->second_wave2 && c->wave2_path && c->wave2_ring && plan->n_first > 0 && plan->n_first < np;
-  const bool fused_two = fused && can_two && !two_runs && (!can_one || c->fused_wgs == 2 || (c->fused_wgs == 0 && plan->fit_two >= 0.75));
+  // One class of pairs: the two-workgroup shape when the work sits in sites that fit its buffer AND most of it in sites of at most
+  // the narrow size -- from about 4 x 4 tiles per site on the 12-wave dual shape is the faster one although the site would still fit
+  // (uniform chains of bond 64, i.e. what a bond cap of 64 produces: dual against two workgroups measured in tools/uniform_ab.py)
+  const bool fused_two = fused && can_two && !two_runs && (!can_one || c->fused_wgs == 2 || (c->fused_wgs == 0 && plan->fit_two >= 0.75 && plan->fit_narrow >= 0.5));
   const size_t lds_fused = (size_t)(fused_two ? QKF_XCAP_TWO : QKF_XCAP_ONE) * 16 + lds_meta;
   const int grid = (int)std::min<long long>(units, (long long)(fused ? (fused_two ? 2 : 1) : c->wgs_per_cu) * c->num_cus);
   const char* dual_env = std::getenv("QK_FUSED_DUAL");

@@ -692,6 +692,25 @@ def test_split_sweep_two_shapes_one_gram(gpu_ctx, monkeypatch):
     assert np.abs(K - K_ref).max() < TOL and np.abs(K - K1).max() < 1e-13 and np.array_equal(K, K.T)
 
 
+def test_one_class_sets_pick_their_shape_by_site_size(gpu_ctx):
+    """A set with ONE class of pairs whose sites all fit the smaller LDS buffer: bonds capped at 48 (3 x 3 tiles per site) stay on
+    the two-workgroup shape, bonds capped at 64 (4 x 4 tiles: what QK_MAX_BOND=64 produces) take the 12-wave dual shape -- the
+    planner's fit_narrow share decides (qk_gram_values); both against the oracle."""
+    import qml_cutensornet_amd as Q
+    from oracle import restatement as R
+
+    rng = np.random.default_rng(47)
+    n = 14
+    for cap, want in ((48, "qk_sweep_fused_kernel<8, 1, 4608, 4>"), (64, "qk_sweep_fused_dual_kernel<12, 8192, 3>")):
+        xs = [Q.random_mps(n, [min(2 ** min(k, n - k), cap) for k in range(n + 1)], rng) for _ in range(6)]
+        K_ref = np.array([[abs(R.mps_inner(x.tensors, y.tensors)) ** 2 for x in xs] for y in xs])
+        with gpu_ctx.upload(xs) as dx:
+            K = gpu_ctx.gram(dx)
+            st = gpu_ctx.stats()
+        assert st["kernel_name"] == want and st["second_kernel"] == 0, (cap, st["kernel_name"])
+        assert np.abs(K - K_ref).max() < TOL and np.array_equal(K, K.T)
+
+
 def test_complex64_storage_wave_sweep(gpu_ctx, monkeypatch):
     """Complex64 sets with bonds <= 32 take qk_sweep_wave2_kernel<3, float>: single-precision STORAGE, fp64 arithmetic.  Its
     result is the fp64 sweep of the rounded tensors -- checked against the oracle ON the rounded tensors to fp64 accuracy --
