@@ -189,7 +189,9 @@ int qk_plan_stats(const qk_plan* plan, qk_stats* out); /* algorithmic flops/byte
  *     pairs, for the one-pair-per-wavefront sweep -- kernel choice is per PAIR, one large state does not drag the rest along;
  *   - otherwise the pairs with >= QK_PLAN_SPLIT (environment, default 0.75) of their padded work in sites that fit the site-fused
  *     kernel's smaller LDS buffer, for its two-workgroups-per-CU shape.
- * == num_pairs when the plan holds (nearly) one class only.                                                              */
+ * == num_pairs when the plan holds (nearly) one class only: the launch then takes the two-workgroups-per-CU shape when >= 75 % of
+ * the padded work sits in sites that fit its buffer AND >= 50 % in sites of at most the narrow size (QK_PLAN_FIT, 3072 elements of
+ * X), the 12-wave dual shape otherwise (e.g. a set whose bonds were cut at 64: every site 4 x 4 tiles).                   */
 int64_t qk_plan_first_run(const qk_plan* plan);
 /* XCD-aware work queues (default plans; QK_PLAN_XCD=0 in the environment or an explicit `block` gives the flat cost-ordered
  * list).  The states are sorted by weight, the Gram is cut into tiles of QK_PLAN_TILE x QK_PLAN_TILE (default 8 x 8) pairs in
