@@ -281,6 +281,30 @@ def test_auto_builder_policy_and_fallback(built, monkeypatch, capsys):
     assert capped.max_bond() == 6 and capped.fidelity < 1 - 1e-6 and Q.simulate(circuits[0], 1 - 1e-16).max_bond() > 6
 
 
+def test_bond_cap_on_the_block_path(gpu_ctx):
+    """A bond cap that bites where the factorisations run on the matrix cores (a gate's theta has 2 chi >= 48 columns): the device
+    builder cut at chi = 32 against the host builder with the same cap (the chi of pytket-cutensornet's Config, ref
+    gpu_backend/kernel_state_ansatz.py:141-144) -- same bonds, same fidelity product, the same states up to the rounding of the
+    singular values at the cut; and the capped states are NOT the uncapped ones."""
+    import qml_cutensornet_amd as Q
+    from oracle import restatement as R
+
+    n, chi = 18, 32
+    X = R.synthetic_features(6, n, 11)
+    ans = Q.KernelStateAnsatz(n, 4, 1.0, Q.entanglement_graph(n, 3))
+    circuits = [ans.circuit_for_data(x) for x in X]
+    host = [Q.simulate(c, 1 - 1e-16, max_bond=chi) for c in circuits]
+    free = Q.simulate(circuits[0], 1 - 1e-16)
+    assert free.max_bond() > chi and max(m.max_bond() for m in host) == chi and min(m.fidelity for m in host) < 1 - 1e-6
+    dev, info = gpu_ctx.build_mps(circuits, max_bond=chi, truncate=True)
+    assert not info["dropped"]
+    for d, h in zip(dev, host):
+        assert np.array_equal(d.bond_dims(), h.bond_dims())
+        assert abs(d.fidelity - h.fidelity) < 1e-9 * max(1.0, h.fidelity)
+        ov = abs(R.mps_inner(d.tensors, h.tensors)) ** 2 / (abs(R.mps_inner(d.tensors, d.tensors)) * abs(R.mps_inner(h.tensors, h.tensors)))
+        assert abs(ov - 1) < 1e-9, ov
+
+
 def _graded(rng, p, q, decades):
     u, _ = np.linalg.qr(rng.standard_normal((p, q)) + 1j * rng.standard_normal((p, q)))
     v, _ = np.linalg.qr(rng.standard_normal((q, q)) + 1j * rng.standard_normal((q, q)))
