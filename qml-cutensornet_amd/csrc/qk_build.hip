@@ -135,6 +135,10 @@ extern "C" int qk_build_mps(qk_ctx* c, int32_t n_states, int32_t n_qubits, int32
   // workgroup per CU with 152 KiB of LDS (qk_build_kernels.h): a heterogeneous data set ends with its few heaviest states, whose
   // block factorisations run one visit per wavefront.  QK_BUILD_WGS=1|2|4 overrides.
   int wgs_variant = (cap <= 32) ? 4 : (cap <= 64 ? 2 : 1);
+  // a share with a workgroup slot per state even in the 512-thread shape (<= one state per CU) ends with its slowest state either
+  // way, and a state is built faster by 512 threads with the whole CU's LDS: 96 states of 100 qubits x 10 layers cut at bond 64,
+  // 60.7 s in the 256-thread shape, 46.8 s in this one (profiles/r03/builder_capped_cfg5_gamma0.5_chi64.txt)
+  if (wgs_variant == 2 && n_states <= c->num_cus) wgs_variant = 1;
   if (const char* v = std::getenv("QK_BUILD_WGS")) wgs_variant = (std::atoi(v) >= 4) ? 4 : (std::atoi(v) <= 1 ? 1 : 2);
   const int bt = wgs_variant == 1 ? 512 : 256;
   size_t lds_total = (wgs_variant == 4 ? 38 : wgs_variant == 2 ? 76 : 152) * 1024;

@@ -281,14 +281,18 @@ def test_auto_builder_policy_and_fallback(built, monkeypatch, capsys):
     assert capped.max_bond() == 6 and capped.fidelity < 1 - 1e-6 and Q.simulate(circuits[0], 1 - 1e-16).max_bond() > 6
 
 
-def test_bond_cap_on_the_block_path(gpu_ctx):
-    """A bond cap that bites where the factorisations run on the matrix cores (a gate's theta has 2 chi >= 48 columns): the device
+@pytest.mark.parametrize("shape", [None, "2", "1"])
+def test_bond_cap_on_the_block_path(gpu_ctx, monkeypatch, shape):
+    """(In each workgroup shape of the builder: four 256-thread workgroups per CU -- the default at this cap --, two, one of 512.)
+    A bond cap that bites where the factorisations run on the matrix cores (a gate's theta has 2 chi >= 48 columns): the device
     builder cut at chi = 32 against the host builder with the same cap (the chi of pytket-cutensornet's Config, ref
     gpu_backend/kernel_state_ansatz.py:141-144) -- same bonds, same fidelity product, the same states up to the rounding of the
     singular values at the cut; and the capped states are NOT the uncapped ones."""
     import qml_cutensornet_amd as Q
     from oracle import restatement as R
 
+    if shape:
+        monkeypatch.setenv("QK_BUILD_WGS", shape)
     n, chi = 18, 32
     X = R.synthetic_features(6, n, 11)
     ans = Q.KernelStateAnsatz(n, 4, 1.0, Q.entanglement_graph(n, 3))
