@@ -84,6 +84,10 @@ typedef struct qk_stats {
    * launch's duration during which the chip was draining -- some workgroups had run out of work, the last one had not.
    * 0 for kernels that do not record it.  At a 1/8 share of the Gram the tails weigh eight times more than on one GPU.   */
   double tail_frac, second_tail_frac;
+  /* Device time between the start of the call and the start of the sweep: the kernels that make a set's derived images
+   * (interleaved image, edge blocks, merged steps) on the FIRST Gram of a set -- part of a cold Gram (the reference's
+   * kernel_mat_time, G:322, 432-434, brackets set-up and tiles alike), ~0 afterwards.                                   */
+  double derive_ms;
 } qk_stats;
 
 /* sweep kernels of qk_gram_values (qk_stats.kernel) */
@@ -212,6 +216,17 @@ int qk_plan_queues(const qk_plan* plan, int64_t* qstart /* [17] */);
  * end; counted by qk_mps_set_info).  This is the host-side choice of the contraction order at the ends of the chain (north star;
  * reference call site G:380); the algorithmic flop count of qk_stats does not change.                                        */
 int32_t qk_plan_edge_sites(const qk_plan* plan);
+/* The plans of ALL world_size ranks from one cost pass (a one-process communicator, qk_gram_sharded: pricing the Gram's pairs and
+ * dealing its tiles is the same work for every rank and is done once; each rank then prices only its own share).  out[world_size];
+ * plan r equals what qk_plan_create(..., world_size, r, 0, ...) returns.  Replaces G:154, 331-334 like qk_plan_create.      */
+int qk_plan_create_all(int32_t n_sites, int32_t nx, const int32_t* x_dims, int32_t ny, const int32_t* y_dims,
+                       uint32_t flags, int32_t world_size, qk_plan** out);
+/* What the plan cost and what it could save.  plan_ms = host wall time of qk_plan_create for this plan (the reference's
+ * kernel_mat_time, G:322, 432-434, brackets the set-up of the tiling phase too: the planner is on the cold path of every Gram),
+ * threads = host threads it used, tile_reuse_bytes = the bytes of this rank's share if every state were read once per plan
+ * tile (8 x 8 pairs) it takes part in -- the tile-reuse lower bound of SURVEY 8d, beside qk_stats.bytes (every state read
+ * once per PAIR).  Any out pointer may be NULL.                                                                          */
+int qk_plan_cost(const qk_plan* plan, double* plan_ms, int32_t* threads, double* tile_reuse_bytes);
 /* MERGED STEPS (no entry point: part of qk_gram_values; QK_MERGE=0 disables).  Between the edge blocks the site-fused sweep may walk
  * two neighbouring sites as ONE step: the set holds, beside its plain image, the chain's sites contracted in twos over the bond between
  * them (tensors [l][4][r], made once per set on first use and counted by qk_mps_set_info), and a workgroup decides per pair and step:

@@ -93,6 +93,7 @@ struct qk_comm {
   std::vector<ncclComm_t> nccl;
   // the job of the last qk_gram_sharded call, kept while the same sets come back (a bench loop re-plans nothing)
   std::vector<const qk_mps_set*> job_x, job_y;
+  std::vector<uint64_t> job_xid, job_yid;  // their uids: a destroyed set's address may be reused by another set
   std::vector<qk_plan*> plans;
   std::vector<DevMem> vals, all_vals, all_pairs, k;
   int64_t maxp = 0;
@@ -103,7 +104,7 @@ struct qk_comm {
 
 static void drop_job(qk_comm* c) {
   for (qk_plan* p : c->plans) qk_plan_destroy(p);
-  c->plans.clear(), c->job_x.clear(), c->job_y.clear();
+  c->plans.clear(), c->job_x.clear(), c->job_y.clear(), c->job_xid.clear(), c->job_yid.clear();
 }
 
 extern "C" int qk_comm_destroy(qk_comm* c) {
@@ -242,8 +243,11 @@ extern "C" int qk_mps_set_allgather(qk_comm* c, qk_mps_set* const* local, const 
 // ---- the sharded Gram: one sweep launch per device, ONE all-gather, a scatter per device ----------------------------
 static int prepare_job(qk_comm* c, qk_mps_set* const* xs, qk_mps_set* const* ys) {
   const int n = c->n;
+  for (int r = 0; r < n; ++r)
+    if (!xs[r] || (ys && !ys[r])) return qk_fail(QK_EINVAL, "qk_gram_sharded: set %d is NULL (every device needs the whole set: qk_mps_set_allgather)", r);
   bool same = (int)c->job_x.size() == n;
-  for (int r = 0; r < n && same; ++r) same = c->job_x[(size_t)r] == xs[r] && c->job_y[(size_t)r] == (ys ? ys[r] : nullptr);
+  for (int r = 0; r < n && same; ++r)
+    same = c->job_x[(size_t)r] == xs[r] && c->job_xid[(size_t)r] == xs[r]->uid && c->job_y[(size_t)r] == (ys ? ys[r] : nullptr) && c->job_yid[(size_t)r] == (ys ? ys[r]->uid : 0);
   if (same) return QK_OK;
   drop_job(c);
   const qk_mps_set* x0 = xs[0];
@@ -251,21 +255,22 @@ static int prepare_job(qk_comm* c, qk_mps_set* const* xs, qk_mps_set* const* ys)
   for (int r = 0; r < n; ++r) {
     const qk_mps_set* x = xs[r];
     const qk_mps_set* y = ys ? ys[r] : nullptr;
-    if (!x || x->ctx != c->ctx[(size_t)r] || (y && y->ctx != c->ctx[(size_t)r])) return qk_fail(QK_EINVAL, "qk_gram_sharded: set %d does not live on the communicator's context %d", r, r);
-    if (x->dims_true != x0->dims_true || (y0 != nullptr) != (y != nullptr) || (y && y->dims_true != y0->dims_true))
+    if (x->ctx != c->ctx[(size_t)r] || (y && y->ctx != c->ctx[(size_t)r])) return qk_fail(QK_EINVAL, "qk_gram_sharded: set %d does not live on the communicator's context %d", r, r);
+    if (x->dims_true != x0->dims_true || (y && y->dims_true != y0->dims_true))
       return qk_fail(QK_EINVAL, "qk_gram_sharded: device %d holds a different set than device 0 (every device needs the whole set: qk_mps_set_allgather)", r);
   }
   const bool sym = y0 == nullptr;
+  // the plans of all ranks from ONE cost pass (this is one process: pass 1 and the deal of the tiles are the same for every rank)
   c->plans.assign((size_t)n, nullptr);
   c->maxp = 1;
-  for (int r = 0; r < n; ++r) {
-    const int rc = qk_plan_create(x0->n_sites, x0->n_states, x0->dims_true.data(), sym ? x0->n_states : y0->n_states, sym ? nullptr : y0->dims_true.data(),
-                                  sym ? (QK_PLAN_SYMMETRIC | QK_PLAN_ORIENT) : 0u, n, r, 0, &c->plans[(size_t)r]);
+  {
+    const int rc = qk_plan_create_all(x0->n_sites, x0->n_states, x0->dims_true.data(), sym ? x0->n_states : y0->n_states, sym ? nullptr : y0->dims_true.data(),
+                                      sym ? (QK_PLAN_SYMMETRIC | QK_PLAN_ORIENT) : 0u, n, c->plans.data());
     if (rc != QK_OK) {
       drop_job(c);
       return rc;
     }
-    c->maxp = std::max<int64_t>(c->maxp, qk_plan_max_pairs_per_rank(c->plans[(size_t)r]));
+    for (int r = 0; r < n; ++r) c->maxp = std::max<int64_t>(c->maxp, qk_plan_max_pairs_per_rank(c->plans[(size_t)r]));
   }
   // the pair table of ALL ranks, padded with -1 (this is one process: no collective needed for it)
   std::vector<int32_t> all((size_t)n * c->maxp * 2, -1);
@@ -284,14 +289,28 @@ static int prepare_job(qk_comm* c, qk_mps_set* const* xs, qk_mps_set* const* ys)
       drop_job(c);
       return rc;
     }
-    HIP_TRY(hipSetDevice(d));
-    HIP_TRY(hipMemcpy(c->all_pairs[(size_t)r].p, all.data(), all.size() * sizeof(int32_t), hipMemcpyHostToDevice));
-    HIP_TRY(hipMemset(c->vals[(size_t)r].p, 0, (size_t)c->maxp * sizeof(double)));
+    hipError_t e = hipSetDevice(d);
+    if (e == hipSuccess) e = hipMemcpy(c->all_pairs[(size_t)r].p, all.data(), all.size() * sizeof(int32_t), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemset(c->vals[(size_t)r].p, 0, (size_t)c->maxp * sizeof(double));
+    if (e != hipSuccess) {
+      drop_job(c);
+      return qk_fail(QK_EDEVICE, "qk_gram_sharded: pair table of device %d: %s", d, hipGetErrorString(e));
+    }
   }
   c->job_x.assign(xs, xs + n);
-  c->job_y.assign((size_t)n, nullptr);
+  c->job_y.assign((size_t)n, nullptr), c->job_xid.assign((size_t)n, 0), c->job_yid.assign((size_t)n, 0);
   if (ys) c->job_y.assign(ys, ys + n);
+  for (int r = 0; r < n; ++r) c->job_xid[(size_t)r] = xs[r]->uid, c->job_yid[(size_t)r] = ys ? ys[r]->uid : 0;
   return QK_OK;
+}
+
+// every context idle again before an error leaves qk_gram_sharded (launches of the other devices may be in flight)
+static int sharded_fail(qk_comm* c, const int rc) {
+  for (int r = 0; r < c->n; ++r) {
+    (void)hipSetDevice(c->devices[(size_t)r]);
+    (void)hipStreamSynchronize(c->ctx[(size_t)r]->stream);
+  }
+  return rc;
 }
 
 extern "C" int qk_gram_sharded(qk_comm* c, qk_mps_set* const* xsets, qk_mps_set* const* ysets, double* out_host, int64_t ld) {
@@ -302,40 +321,49 @@ extern "C" int qk_gram_sharded(qk_comm* c, qk_mps_set* const* xsets, qk_mps_set*
   const bool sym = ysets == nullptr;
   const int nx = xsets[0]->n_states, ny = sym ? nx : ysets[0]->n_states;
   if (out_host && ld < nx) return qk_fail(QK_EINVAL, "qk_gram_sharded: ld %lld < %d columns", (long long)ld, nx);
-  // 1. every device sweeps its share (asynchronous launches: the devices run concurrently)
-  qk_range_push("qk:sharded_sweep");
-  for (int r = 0; r < n && rc == QK_OK; ++r) {
-    HIP_TRY(hipSetDevice(c->devices[(size_t)r]));
-    HIP_TRY(hipMemsetAsync(c->k[(size_t)r].p, 0, (size_t)nx * ny * sizeof(double), c->ctx[(size_t)r]->stream));
-    rc = qk_gram_values(c->ctx[(size_t)r], xsets[r], sym ? nullptr : ysets[r], c->plans[(size_t)r], c->vals[(size_t)r].as<double>(), nullptr);
+  auto hip_ok = [](const hipError_t e, const char* what) { return e == hipSuccess ? QK_OK : qk_fail(QK_EDEVICE, "qk_gram_sharded: %s: %s", what, hipGetErrorString(e)); };
+  // 1. every device sweeps its share.  Everything here is asynchronous -- on a set's first Gram that includes the kernels that make its
+  //    derived images (interleaved, edge blocks, merged steps) --, so all devices are at work before the host waits for any of them
+  {
+    QkRangeGuard range_("qk:sharded_sweep");
+    for (int r = 0; r < n && rc == QK_OK; ++r) {
+      rc = hip_ok(hipSetDevice(c->devices[(size_t)r]), "hipSetDevice");
+      if (rc == QK_OK) rc = hip_ok(hipMemsetAsync(c->k[(size_t)r].p, 0, (size_t)nx * ny * sizeof(double), c->ctx[(size_t)r]->stream), "hipMemsetAsync");
+      if (rc == QK_OK) rc = qk_gram_values(c->ctx[(size_t)r], xsets[r], sym ? nullptr : ysets[r], c->plans[(size_t)r], c->vals[(size_t)r].as<double>(), nullptr);
+    }
   }
-  qk_range_pop();
-  if (rc != QK_OK) return rc;
+  if (rc != QK_OK) return sharded_fail(c, rc);
   // 2. the ONE collective of the path: all-gather of the packed values over xGMI
-  qk_range_push("qk:allgather_values");
-  HIP_TRY(hipSetDevice(c->devices[0]));
-  HIP_TRY(hipEventRecord(c->ev0, c->ctx[0]->stream));
-  ncclResult_t nr = rccl().GroupStart();
-  for (int r = 0; r < n && nr == ncclSuccess; ++r)
-    nr = rccl().AllGather(c->vals[(size_t)r].p, c->all_vals[(size_t)r].p, (size_t)c->maxp, ncclDouble, c->nccl[(size_t)r], c->ctx[(size_t)r]->stream);
-  const ncclResult_t ne = rccl().GroupEnd();
-  if (nr == ncclSuccess) nr = ne;
-  if (nr != ncclSuccess) return qk_fail(QK_EDEVICE, "qk_gram_sharded: ncclAllGather failed: %s", rccl().GetErrorString(nr));
-  HIP_TRY(hipSetDevice(c->devices[0]));
-  HIP_TRY(hipEventRecord(c->ev1, c->ctx[0]->stream));
-  qk_range_pop();
+  {
+    QkRangeGuard range_("qk:allgather_values");
+    rc = hip_ok(hipSetDevice(c->devices[0]), "hipSetDevice");
+    if (rc == QK_OK) rc = hip_ok(hipEventRecord(c->ev0, c->ctx[0]->stream), "hipEventRecord");
+    if (rc != QK_OK) return sharded_fail(c, rc);
+    ncclResult_t nr = rccl().GroupStart();
+    for (int r = 0; r < n && nr == ncclSuccess; ++r)
+      nr = rccl().AllGather(c->vals[(size_t)r].p, c->all_vals[(size_t)r].p, (size_t)c->maxp, ncclDouble, c->nccl[(size_t)r], c->ctx[(size_t)r]->stream);
+    const ncclResult_t ne = rccl().GroupEnd();
+    if (nr == ncclSuccess) nr = ne;
+    if (nr != ncclSuccess) return sharded_fail(c, qk_fail(QK_EDEVICE, "qk_gram_sharded: ncclAllGather failed: %s", rccl().GetErrorString(nr)));
+    rc = hip_ok(hipSetDevice(c->devices[0]), "hipSetDevice");
+    if (rc == QK_OK) rc = hip_ok(hipEventRecord(c->ev1, c->ctx[0]->stream), "hipEventRecord");
+    if (rc != QK_OK) return sharded_fail(c, rc);
+  }
   // 3. every device fills (and mirrors) its own dense K; rank 0's goes to the caller
   for (int r = 0; r < n && rc == QK_OK; ++r)
     rc = qk_scatter(c->ctx[(size_t)r], c->all_pairs[(size_t)r].as<int32_t>(), c->all_vals[(size_t)r].as<double>(), (int64_t)n * c->maxp, c->k[(size_t)r].as<double>(), nx, sym ? 1 : 0);
-  if (rc != QK_OK) return rc;
-  if (out_host) {
-    HIP_TRY(hipSetDevice(c->devices[0]));
-    HIP_TRY(hipMemcpy2DAsync(out_host, (size_t)ld * sizeof(double), c->k[0].p, (size_t)nx * sizeof(double), (size_t)nx * sizeof(double), (size_t)ny, hipMemcpyDeviceToHost, c->ctx[0]->stream));
+  if (rc == QK_OK && out_host) {
+    rc = hip_ok(hipSetDevice(c->devices[0]), "hipSetDevice");
+    if (rc == QK_OK)
+      rc = hip_ok(hipMemcpy2DAsync(out_host, (size_t)ld * sizeof(double), c->k[0].p, (size_t)nx * sizeof(double), (size_t)nx * sizeof(double), (size_t)ny, hipMemcpyDeviceToHost, c->ctx[0]->stream),
+                  "hipMemcpy2DAsync");
   }
+  if (rc != QK_OK) return sharded_fail(c, rc);
   for (int r = 0; r < n; ++r) {
-    rc = qk_ctx_synchronize(c->ctx[(size_t)r]);
-    if (rc != QK_OK) return rc;
+    const int rs = qk_ctx_synchronize(c->ctx[(size_t)r]);
+    if (rs != QK_OK && rc == QK_OK) rc = rs;  // (keep waiting for the others)
   }
+  if (rc != QK_OK) return rc;
   float ms = 0;
   HIP_TRY(hipSetDevice(c->devices[0]));
   HIP_TRY(hipEventElapsedTime(&ms, c->ev0, c->ev1));

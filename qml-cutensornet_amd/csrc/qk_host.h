@@ -4,13 +4,13 @@
 //   qk_lab.hip    experimental / diagnostic kernels for A/B measurements: only in lab/libqklab.so (-DQK_LAB, lab/tools)
 #pragma once
 #include "../../include/qkgram.h"
+#include "qk_plan.h"
 
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
 #include <vector>
 
-int qk_fail(int code, const char* fmt, ...) __attribute__((format(printf, 2, 3)));  // sets qk_last_error(), returns code
 struct QkRangeGuard {  // a roctx range (qk_range_push / qk_range_pop) that closes on every exit path
   explicit QkRangeGuard(const char* n) { qk_range_push(n); }
   ~QkRangeGuard() { qk_range_pop(); }
@@ -31,6 +31,7 @@ struct qk_ctx {
   hipStream_t stream = nullptr;
   bool split_pending = false;  // the last sweep was two launches: second_ms is still to be read from the events
   hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_mid = nullptr;  // ev_mid: between the two launches of a split sweep
+  hipEvent_t ev_d = nullptr;  // at the start of qk_gram_values: what runs between it and ev0 are the kernels that make a set's derived images (first Gram of a set)
   bool ev_pending = false;
   double* scratch = nullptr;
   size_t scratch_bytes = 0;
@@ -55,10 +56,16 @@ struct qk_ctx {
   size_t build_arena_bytes = 0;
   void* build_work = nullptr;
   size_t build_work_bytes = 0;
+  // scratch of the workgroups that make a set's edge blocks (qk_edge_kernel), kept between calls
+  void* derive_tmp = nullptr;
+  size_t derive_tmp_bytes = 0;
 };
+
+uint64_t qk_next_uid();
 
 struct qk_mps_set {
   qk_ctx* ctx = nullptr;
+  uint64_t uid = qk_next_uid();  // unique per set of this process: caches keyed on a set's address also compare this (a freed address may come back)
   int n_states = 0, n_sites = 0, max_pad = 0;
   int precision = 64;         // bits of a real: 64 (complex128 planes) or 32 (complex64 planes, same element offsets)
   double* d_data = nullptr;   // the planes; floats when precision == 32
@@ -77,34 +84,12 @@ struct qk_mps_set {
   // contracted in twos, interleaved complex [l][4][r]
   double* d_mg = nullptr;
   int64_t* d_mg_offs = nullptr;  // offsets in doubles [n_states][mg_steps]
+  long long* d_mg_units = nullptr;  // first 16 x 16 block of each (state, step) in the numbering of qk_merge_kernel's units [n_states * mg_steps + 1]
+  std::vector<long long> h_edge_offs, h_mg_units;  // host staging of the tables above (they outlive the asynchronous copies)
+  std::vector<int64_t> h_mg_offs;
   int mg_k = -1, mg_steps = 0;
   int64_t mg_bytes = 0;
 };
-
-struct qk_plan {
-  int n_sites = 0, nx = 0, ny = 0;
-  bool symmetric = false;
-  bool quad = false;  // pairs come in 2x2 blocks (QK_PLAN_QUADS): [4q..4q+3] = (i1,j1), (i2,j1), (i1,j2), (i2,j2)
-  int world = 1, rank = 0;
-  int64_t total_pairs = 0, max_per_rank = 0;
-  std::vector<int32_t> pairs;   // this rank, (i, j) interleaved
-  std::vector<int32_t> groups;  // (first pair, count): runs of <= group pairs that share the x state
-  int group = 1;
-  qk_stats stats{};
-  qk_stats second{};       // pairs / flops / padded_flops / bytes of the class-1 run [n_first, end)
-  int64_t n_first = 0;     // pairs [n_first, end) are the class whose sites fit the fused sweep's smaller LDS buffer (== number of pairs: no split)
-  int nq = 1;                 // device work queues: 1 = one list; 16 = two classes of pairs x 8 XCD queues (the second class may be empty)
-  int64_t qstart[17] = {0};   // queue s = pairs [qstart[s], qstart[s + 1]) of this rank's list; queues 8..15 = the class-1 run
-  int edge_k = 0;             // sites at either end of the chain that the fused sweep takes from the sets' edge blocks (0: none)
-  bool second_wave2 = false;  // the second run holds the pairs of two states whose bonds are all <= 32: swept by the one-wave kernel (mixed sets)
-  double fit_two = 1.0;  // share of this rank's padded work in sites whose X and X' fit the fused sweep's smaller LDS buffer
-  double fit_narrow = 1.0;  // ... in sites of at most the narrow size (QK_PLAN_FIT: where the two-workgroup shape still beats the 12-wave dual one)
-  // lazily uploaded copy
-  qk_ctx* up_ctx = nullptr;
-  int32_t* d_pairs = nullptr;
-  int32_t* d_groups = nullptr;
-};
-
 
 struct SweepArgs;
 // qk_lab.hip: raise the LDS limit of the lab kernels; launch lab variant `variant` (returns QK_EINVAL if it is not one)

@@ -48,6 +48,12 @@ int qk_fail(int code, const char* fmt, ...) {
 
 extern "C" const char* qk_last_error(void) { return g_err.c_str(); }
 
+#include <atomic>
+uint64_t qk_next_uid() {
+  static std::atomic<uint64_t> next{1};
+  return next.fetch_add(1);
+}
+
 // ----------------------------------------------------------------------------------------
 // roctx ranges around the phases of the path (build / upload / sweep / all-gather / scatter: the reference's timing sites
 // G:379-381 and its profiling keys), so that ONE `rocprofv3 --marker-trace --kernel-trace` run yields the phase table.
@@ -141,14 +147,8 @@ extern "C" int qk_pack_state(int32_t n_sites, const int32_t* bond_dims, const do
 }
 
 // ----------------------------------------------------------------------------------------
-// host: work model and planner
+// The planner (work model, contraction order, tiles, ranks, queues) is qk_planner.cpp; the launch shapes it plans for:
 // ----------------------------------------------------------------------------------------
-// Algorithmic flops of one overlap: 8 real flops per complex
-// multiply-add, cheaper association per site.  Padded: what this engine executes.
-#ifndef QKF_XCAP_ONE_V
-#define QKF_XCAP_ONE_V 8192
-#endif
-static constexpr int QKF_XCAP_ONE = QKF_XCAP_ONE_V, QKF_XCAP_TWO = 4608;  // elements of the fused sweep's LDS X buffer with one / two workgroups per CU
 // shapes of the two instantiations: waves per workgroup, T slots per wave, waves per SIMD (experiment builds override them)
 #ifndef QKF_ONE_NW
 #define QKF_ONE_NW 12  // three waves per SIMD at 168 VGPRs: 452 against 482 ms for 8 waves x 4 slots on the headline set (16 x 1: 455)
@@ -167,477 +167,6 @@ static constexpr int QKF_XCAP_ONE = QKF_XCAP_ONE_V, QKF_XCAP_TWO = 4608;  // ele
 #define QKF_DUAL_WPS 3
 #endif
 #define QKF_KERNEL_DUAL qk_sweep_fused_dual_kernel<QKF_DUAL_NW, QKF_XCAP_ONE, QKF_DUAL_WPS>
-// The narrow site size of the pair classes (QK_PLAN_FIT, elements of X): when a set holds a substantial share of LARGE pairs, only
-// pairs whose work sits in sites of at most this many elements go to the two-workgroup shape -- the 12-wave dual shape is the
-// better one from about 4 x 4 tiles per site on (uniform chains: bond 48 39.8 against 42.4 ms for the two-workgroup shape, bond 64
-// 99.8 against 86.6 ms).  60 qubits x 6 layers, whole sweep: 4608 (every site that fits the smaller buffer) 377.0 ms, 3584 365.9,
-// 3072 365.6, 2560 and below (one launch of the dual shape) 368.1.  A set without large pairs (40 qubits x 4 layers) stays on the
-// two-workgroup shape as a whole: 12.65 ms against 13.1-13.2 when split at the narrow size.
-static double g_plan_fit = 3072;  // (set by qk_plan_create)
-static void pair_work(int n, const int32_t* a, const int32_t* b, double* flops, double* padded, double* bytes, double* fit_two = nullptr, double* fit_narrow = nullptr) {
-  double f = 0, fp = 0, by = 0, ft = 0, fn = 0;
-  for (int k = 0; k < n; ++k) {
-    const double a0 = a[k], a1 = a[k + 1], b0 = b[k], b1 = b[k + 1];
-    const double f1 = a0 * b0 * 2 * b1 + 2 * a0 * a1 * b1;
-    const double f2 = a0 * b0 * 2 * a1 + 2 * b0 * a1 * b1;
-    f += 8 * std::min(f1, f2);
-    const double A0 = pad16(a[k]), A1 = pad16(a[k + 1]), B0 = pad16(b[k]), B1 = pad16(b[k + 1]);
-    fp += 8 * (A0 * B0 * 2 * B1 + 2 * A0 * A1 * B1);
-    if (A0 * B0 <= QKF_XCAP_TWO && A1 * B1 <= QKF_XCAP_TWO) ft += 8 * (A0 * B0 * 2 * B1 + 2 * A0 * A1 * B1);  // X and X' of this site fit the smaller buffer
-    if (A0 * B0 <= g_plan_fit && A1 * B1 <= g_plan_fit) fn += 8 * (A0 * B0 * 2 * B1 + 2 * A0 * A1 * B1);      // ... with room to spare (see g_plan_fit)
-    by += 16.0 * 2 * (a0 * a1 + b0 * b1);
-  }
-  if (fit_two) *fit_two = ft;
-  if (fit_narrow) *fit_narrow = fn;
-  *flops = f;
-  *padded = fp;
-  *bytes = by + 8;
-}
-
-// Matrix instructions the site-fused sweep issues for the pair (x = a, y = b): per site (a^/16)(b'^/16) tiles of T, each
-// ceil(b/4) k-steps in phase 1 and (a'^/16) column blocks x ceil(a/4)-bounded k-steps in phase 2 (x 3 for the 3M product,
-// x 2 for p).  The ring sweep's padded flops follow the same asymmetry, so one model serves both.
-static double fused_cost(int n, const int32_t* a, const int32_t* b) {
-  double c = 0;
-  for (int k = 0; k < n; ++k) {
-    const double A0 = pad16(a[k]) / 16, A1 = pad16(a[k + 1]) / 16, B1 = pad16(b[k + 1]) / 16;
-    const double kb = (b[k] + 3) / 4, ka = (a[k] + 3) / 4;
-    c += 6 * A0 * B1 * kb + 6 * B1 * A1 * ka;
-  }
-  return c;
-}
-
-// How many sites at either end of the chain the site-fused sweep should take from edge blocks (qk_fused.h: qkf_edge_prefix /
-// qkf_edge_suffix) instead of walking them: the k that minimises, over a sample of this rank's pairs, the matrix instructions of
-// the sweep plus a fixed cost per site walked (two barriers, set-up, load latencies: 375 instructions' worth = 2.5 us of a 12-wave
-// workgroup, measured on uniform small chains, tools/site_overhead.py).  A block product costs tiles(a_k) tiles(b_k) 2^k / 4 x 3
-// instructions x 2 (its tiles stream both blocks from L2).  Calibrated on the two headline sets with merged steps in the middle of
-// the chain: 60 qubits x 6 layers, k = 6 / 7 / 8 / 9 measured 403.8 / 393.8 / 396.2 / 401.8 ms (model, relative to k = 8: 1.008 /
-// 0.997 / 1 / 1.036); 40 qubits x 4 layers, k = 5 .. 9: 13.23 / 13.11 / 12.80 / 12.85 / 13.83 ms (model 1.054 / 1.021 / 0.995 / 1 /
-// 1.087).  Before the merged steps (every site of the middle walked singly) k = 8 was the minimum, at factor 1.5; the chain's cost is fused_cost's.  QK_EDGE=0 disables, QK_EDGE=k forces.  This is a contraction order chosen on the
-// host (north star; reference call site G:380): while the bonds still grow like 2^k, the ends of the two states are cheaper to
-// contract across their physical legs than along the chain.
-static int choose_edge_k(const int n_sites, const int32_t* x_dims, const int32_t* y_dims, const std::vector<int32_t>& pairs) {
-  constexpr int KMIN = 4, KMAX = 9;  // K = 2^k >= 16 (four k-steps in flight); 2^9 rows per block at most
-  if (const char* e = std::getenv("QK_EDGE")) {
-    const int v = std::atoi(e);
-    if (v <= 0) return 0;
-    return (v >= KMIN && v <= KMAX && n_sites >= 2 * v + 2) ? v : 0;
-  }
-  const int64_t np = (int64_t)pairs.size() / 2;
-  if (np == 0 || n_sites < 2 * KMIN + 2) return 0;
-  const int stride = n_sites + 1;
-  const int64_t step = std::max<int64_t>(1, np / 512);
-  const double over = 375.0;
-  auto t16 = [](const int v) { return (double)((v + 15) / 16); };
-  std::vector<double> total((size_t)KMAX + 1, 0.0);
-  for (int64_t t = 0; t < np; t += step) {
-    const int32_t* a = x_dims + (int64_t)pairs[2 * t] * stride;
-    const int32_t* b = y_dims + (int64_t)pairs[2 * t + 1] * stride;
-    std::vector<double> site((size_t)n_sites);
-    for (int k = 0; k < n_sites; ++k)
-      site[(size_t)k] = 6 * t16(a[k]) * t16(b[k + 1]) * ((b[k] + 3) / 4) + 6 * t16(b[k + 1]) * t16(a[k + 1]) * ((a[k] + 3) / 4) + over;
-    double chain = 0;
-    for (double v : site) chain += v;
-    total[0] += chain;
-    double ends = 0;  // cost of the sites the edges replace
-    for (int k = 1; k <= KMAX && n_sites >= 2 * k + 2; ++k) {
-      ends += site[(size_t)k - 1] + site[(size_t)(n_sites - k)];
-      if (k < KMIN) continue;
-      const double blocks = 2.0 * 3.0 * ((1 << k) / 4) * (t16(a[k]) * t16(b[k]) + t16(a[n_sites - k]) * t16(b[n_sites - k])) + 2 * over;
-      total[(size_t)k] += chain - ends + blocks;
-    }
-  }
-  int best = 0;
-  for (int k = KMIN; k <= KMAX && n_sites >= 2 * k + 2; ++k)
-    if (total[(size_t)k] > 0 && total[(size_t)k] < total[(size_t)best] * 0.995) best = k;
-  return best;
-}
-
-// ----------------------------------------------------------------------------------------
-// The tiled plan: XCD-aware work queues (default; QK_PLAN_XCD=0 or an explicit locality `block` selects the flat list).
-// An MI355X has 8 XCDs with a private 4 MiB L2 each, and blocks are dealt to them round-robin.  With one cost-ordered list
-// the 32 (or 64) workgroups that share an L2 stream 64 unrelated states through it (measured hit rate 39 %, 2.5-3 x the
-// algorithmic bytes at the L2 <-> fabric boundary).  Here the states are sorted by weight, the Gram is cut into tiles of T x T
-// pairs in that order -- pairs of a tile share their T x states and T y states and cost about the same, so the workgroups
-// sweeping a tile walk the chain at a similar pace --, the tiles are dealt (heaviest first, to the least loaded) to the
-// ranks and, per class of pairs, to 8 queues; a workgroup drains the queue of its own XCD and then steals (qk_pull).
-// ----------------------------------------------------------------------------------------
-static void plan_tiled(qk_plan* p, const int n_sites, const int nx, const int32_t* x_dims, const int ny, const int32_t* y_dims, const bool sym, const bool orient, const int world,
-                       const int rank, const int T) {
-  const int stride = n_sites + 1;
-  auto order_of = [&](const int n, const int32_t* dims) {
-    std::vector<double> w((size_t)n);
-    for (int s = 0; s < n; ++s) {
-      const int32_t* d = dims + (int64_t)s * stride;
-      double acc = 0;
-      for (int k = 0; k < n_sites; ++k) {
-        const double A0 = pad16(d[k]), A1 = pad16(d[k + 1]);
-        acc += A0 * A1 * (A0 + A1);
-      }
-      w[(size_t)s] = acc;
-    }
-    std::vector<int> o((size_t)n);
-    std::iota(o.begin(), o.end(), 0);
-    std::stable_sort(o.begin(), o.end(), [&](const int u, const int v) { return w[(size_t)u] > w[(size_t)v]; });
-    return o;
-  };
-  const std::vector<int> ox = order_of(nx, x_dims), oy = sym ? ox : order_of(ny, y_dims);
-  struct Item {
-    int32_t i, j;
-    double f, fp, by, ft, fn;
-  };
-  struct Tile {
-    int64_t start, count;
-    double cost;
-  };
-  std::vector<Item> items;
-  std::vector<Tile> tiles;
-  const int nbx = (nx + T - 1) / T, nby = (ny + T - 1) / T;
-  for (int bj = 0; bj < nby; ++bj)
-    for (int bi = 0; bi < nbx; ++bi) {
-      if (sym && bi > bj) continue;
-      Tile t{(int64_t)items.size(), 0, 0.0};
-      for (int v = bj * T; v < std::min(ny, (bj + 1) * T); ++v)
-        for (int u = bi * T; u < std::min(nx, (bi + 1) * T); ++u) {
-          if (sym && u > v) continue;  // positions in the weight order: every unordered pair once
-          int xi = ox[(size_t)u], yj = oy[(size_t)v];
-          if (sym && !orient && xi > yj) std::swap(xi, yj);  // the plain symmetric list names a pair as i <= j
-          if (orient && xi != yj && fused_cost(n_sites, x_dims + (int64_t)yj * stride, y_dims + (int64_t)xi * stride) < fused_cost(n_sites, x_dims + (int64_t)xi * stride, y_dims + (int64_t)yj * stride))
-            std::swap(xi, yj);
-          Item it{xi, yj, 0, 0, 0, 0};
-          pair_work(n_sites, x_dims + (int64_t)xi * stride, y_dims + (int64_t)yj * stride, &it.f, &it.fp, &it.by, &it.ft, &it.fn);
-          items.push_back(it);
-          t.cost += it.fp;
-        }
-      t.count = (int64_t)items.size() - t.start;
-      if (t.count) tiles.push_back(t);
-    }
-  std::vector<int> by_cost(tiles.size());
-  std::iota(by_cost.begin(), by_cost.end(), 0);
-  std::stable_sort(by_cost.begin(), by_cost.end(), [&](const int u, const int v) { return tiles[(size_t)u].cost > tiles[(size_t)v].cost; });
-  if (world > 1) {
-    // several ranks: the lightest tiles (the last 3 % of the work) are dealt pair by pair, so that the shares end level to a
-    // pair's cost instead of a tile's (cut into one-pair tiles here; they keep their place behind the whole tiles)
-    double total = 0, acc = 0;
-    for (const Tile& t : tiles) total += t.cost;
-    std::vector<Tile> cut;
-    std::vector<int> order;
-    for (const int t : by_cost) {
-      acc += tiles[(size_t)t].cost;
-      if (acc <= 0.97 * total || tiles[(size_t)t].count == 1) {
-        order.push_back((int)cut.size());
-        cut.push_back(tiles[(size_t)t]);
-      } else {
-        std::vector<int64_t> q((size_t)tiles[(size_t)t].count);
-        std::iota(q.begin(), q.end(), tiles[(size_t)t].start);
-        std::stable_sort(q.begin(), q.end(), [&](const int64_t u, const int64_t v) { return items[(size_t)u].fp > items[(size_t)v].fp; });
-        for (const int64_t e : q) {
-          order.push_back((int)cut.size());
-          cut.push_back(Tile{e, 1, items[(size_t)e].fp});
-        }
-      }
-    }
-    tiles.swap(cut), by_cost.swap(order);
-    std::stable_sort(by_cost.begin(), by_cost.end(), [&](const int u, const int v) { return tiles[(size_t)u].cost > tiles[(size_t)v].cost; });
-  }
-  // tiles to ranks: heaviest first, each to the least loaded rank
-  std::vector<double> load((size_t)world, 0.0);
-  std::vector<int64_t> per_rank((size_t)world, 0);
-  std::vector<int> mine;
-  for (const int t : by_cost) {
-    const int r = (int)(std::min_element(load.begin(), load.end()) - load.begin());
-    load[(size_t)r] += tiles[(size_t)t].cost, per_rank[(size_t)r] += tiles[(size_t)t].count;
-    if (r == rank) mine.push_back(t);
-  }
-  // classes of this rank's pairs (see qk_plan_create): class 1 = nearly all of the work fits the fused sweep's smaller LDS buffer
-  double split = 0.75;
-  if (const char* e = std::getenv("QK_PLAN_SPLIT")) split = std::atof(e);
-  double flops = 0, padded = 0, bytes = 0, fit_two = 0, fit_narrow = 0, small_work = 0;
-  for (const int t : mine)
-    for (int64_t q = tiles[(size_t)t].start; q < tiles[(size_t)t].start + tiles[(size_t)t].count; ++q) {
-      const Item& it = items[(size_t)q];
-      flops += it.f, padded += it.fp, bytes += it.by, fit_two += it.ft, fit_narrow += it.fn;
-      if (it.fp > 0 && it.ft >= split * it.fp) small_work += it.fp;
-    }
-  // A MIXED set -- some states with every bond <= 32 next to larger ones -- keeps its small-small pairs on the one-wave sweep
-  // (2 x 2 register tiles, 2-3 x faster per such pair than the multi-wave kernels): they form the second run instead, swept by
-  // qk_sweep_wave2_kernel right behind the fused launch.  (A set whose bonds are all <= 32 runs that kernel anyway.)
-  auto max_pad_of = [&](const int n, const int32_t* dims) {
-    std::vector<int> mp((size_t)n, 0);
-    for (int s_ = 0; s_ < n; ++s_)
-      for (int k = 0; k <= n_sites; ++k) mp[(size_t)s_] = std::max(mp[(size_t)s_], pad16(dims[(int64_t)s_ * stride + k]));
-    return mp;
-  };
-  const std::vector<int> mpx = max_pad_of(nx, x_dims), mpy = sym ? mpx : max_pad_of(ny, y_dims);
-  const bool any_large = *std::max_element(mpx.begin(), mpx.end()) > 32 || *std::max_element(mpy.begin(), mpy.end()) > 32;
-  auto small_pair = [&](const Item& it) { return mpx[(size_t)it.i] <= 32 && mpy[(size_t)it.j] <= 32; };
-  int64_t n_small_pairs = 0, n_mine = 0;
-  for (const int t : mine)
-    for (int64_t q = tiles[(size_t)t].start; q < tiles[(size_t)t].start + tiles[(size_t)t].count; ++q) n_small_pairs += small_pair(items[(size_t)q]) ? 1 : 0, ++n_mine;
-  const bool mixed = any_large && n_small_pairs >= std::max<int64_t>(64, n_mine / 50) && n_small_pairs < n_mine && !std::getenv("QK_PLAN_NO_MIXED");
-  p->second_wave2 = mixed;
-  const bool two_classes = mixed || !(small_work < 0.05 * padded || small_work > 0.95 * padded);
-  // with a quarter or more of the work in large pairs the second class is cut at the narrow site size (g_plan_fit)
-  const bool narrow = !mixed && two_classes && small_work < 0.75 * padded;
-  auto cls_of = [&](const Item& it) {
-    return mixed ? (small_pair(it) ? 1 : 0) : ((two_classes && it.fp > 0 && (narrow ? it.fn : it.ft) >= split * it.fp) ? 1 : 0);
-  };
-  p->pairs.clear(), p->groups.clear();
-  p->second = qk_stats{};
-  p->nq = QK_NQ_MAX;
-  for (int c = 0; c < 2; ++c) {
-    // this class's share of each tile, tiles to the 8 queues heaviest first / least loaded
-    std::vector<std::pair<double, int>> part;  // (class-c cost of the tile, tile)
-    for (const int t : mine) {
-      double cc = 0;
-      for (int64_t q = tiles[(size_t)t].start; q < tiles[(size_t)t].start + tiles[(size_t)t].count; ++q)
-        if (cls_of(items[(size_t)q]) == c) cc += items[(size_t)q].fp;
-      if (cc > 0) part.push_back({cc, t});
-    }
-    std::stable_sort(part.begin(), part.end(), [](const std::pair<double, int>& u, const std::pair<double, int>& v) { return u.first > v.first; });
-    std::vector<double> ql(8, 0.0);
-    std::vector<std::vector<int>> queue(8);
-    for (const auto& pt : part) {
-      const int qd = (int)(std::min_element(ql.begin(), ql.end()) - ql.begin());
-      ql[(size_t)qd] += pt.first;
-      queue[(size_t)qd].push_back(pt.second);
-    }
-    for (int qd = 0; qd < 8; ++qd) {
-      p->qstart[8 * c + qd] = (int64_t)p->pairs.size() / 2;
-      for (const int t : queue[(size_t)qd])
-        for (int64_t q = tiles[(size_t)t].start; q < tiles[(size_t)t].start + tiles[(size_t)t].count; ++q) {
-          const Item& it = items[(size_t)q];
-          if (cls_of(it) != c) continue;
-          p->groups.push_back((int32_t)(p->pairs.size() / 2));
-          p->groups.push_back(1);
-          p->pairs.push_back(it.i);
-          p->pairs.push_back(it.j);
-          if (c == 1) p->second.pairs += 1, p->second.flops += it.f, p->second.padded_flops += it.fp, p->second.bytes += it.by;
-        }
-    }
-  }
-  const int64_t np = (int64_t)p->pairs.size() / 2;
-  p->qstart[16] = np;
-  p->group = 1;
-  p->n_first = p->qstart[8];  // == np when there is one class
-  p->total_pairs = (int64_t)items.size();
-  p->max_per_rank = *std::max_element(per_rank.begin(), per_rank.end());
-  p->stats.pairs = np;
-  p->stats.flops = flops, p->stats.padded_flops = padded, p->stats.bytes = bytes;
-  p->fit_two = padded > 0 ? fit_two / padded : 1.0;
-  p->fit_narrow = padded > 0 ? fit_narrow / padded : 1.0;
-  p->edge_k = choose_edge_k(n_sites, x_dims, y_dims, p->pairs);
-}
-
-extern "C" int qk_plan_create(int32_t n_sites, int32_t nx, const int32_t* x_dims, int32_t ny, const int32_t* y_dims,
-                              uint32_t flags, int32_t world_size, int32_t rank, int32_t block, qk_plan** out) {
-  if (!out || !x_dims || n_sites <= 0 || nx <= 0) return fail(QK_EINVAL, "qk_plan_create: bad argument");
-  const bool sym = (flags & QK_PLAN_SYMMETRIC) != 0;
-  const bool orient = sym && (flags & QK_PLAN_ORIENT) != 0 && !(flags & QK_PLAN_QUADS);
-  if (sym) {
-    y_dims = x_dims;
-    ny = nx;
-  } else if (!y_dims || ny <= 0)
-    return fail(QK_EINVAL, "qk_plan_create: y_dims required unless symmetric");
-  if (world_size <= 0 || rank < 0 || rank >= world_size) return fail(QK_EINVAL, "qk_plan_create: bad rank %d/%d", rank, world_size);
-  {
-    const char* e = std::getenv("QK_PLAN_FIT");
-    g_plan_fit = e ? std::atof(e) : 3072.0;
-  }
-  const int block_arg = block;
-  if (block <= 0) block = std::max(nx, ny);  // flat list (QK_PLAN_XCD=0): the whole pair list in cost order
-  qk_plan* p = new (std::nothrow) qk_plan;
-  if (!p) return fail(QK_ENOMEM, "qk_plan_create: out of memory");
-  p->n_sites = n_sites, p->nx = nx, p->ny = ny, p->symmetric = sym, p->world = world_size, p->rank = rank;
-
-  struct Item {
-    int32_t i, j;
-    float cost;
-    int32_t tile = 0;
-    int32_t cls = 0;  // 1: nearly all of the pair's work sits in sites that fit the fused sweep's smaller LDS buffer
-  };
-  if (flags & QK_PLAN_QUADS) {
-    // 2x2 blocks of pairs {i1, i2} x {j1, j2} (duos of consecutive states; the last duo of an odd set names its state
-    // twice).  A symmetric Gram takes the duo pairs u <= v; its diagonal blocks then hold one mirrored pair (i > j) that
-    // is computed redundantly.  Blocks are ordered by decreasing cost and dealt in serpentine order like pairs.
-    p->quad = true;
-    const int stride = n_sites + 1;
-    const int nxd = (nx + 1) / 2, nyd = (ny + 1) / 2;
-    struct Quad {
-      int32_t i1, i2, j1, j2;
-      double cost;
-    };
-    std::vector<Quad> quads;
-    auto work = [&](int i, int j, double* f, double* fp, double* by) { pair_work(n_sites, x_dims + (int64_t)i * stride, y_dims + (int64_t)j * stride, f, fp, by); };
-    for (int v = 0; v < nyd; ++v)
-      for (int u = 0; u < nxd; ++u) {
-        if (sym && u > v) continue;
-        Quad q{2 * u, std::min(2 * u + 1, nx - 1), 2 * v, std::min(2 * v + 1, ny - 1), 0.0};
-        const int32_t is[2] = {q.i1, q.i2}, js[2] = {q.j1, q.j2};
-        for (int b = 0; b < 2; ++b)
-          for (int a = 0; a < 2; ++a) {
-            double f, fp, by;
-            work(is[a], js[b], &f, &fp, &by);
-            q.cost += fp;
-          }
-        quads.push_back(q);
-      }
-    std::stable_sort(quads.begin(), quads.end(), [](const Quad& a, const Quad& b) { return a.cost > b.cost; });
-    std::vector<int64_t> per_rank(world_size, 0);
-    double flops = 0, padded = 0, bytes = 0;
-    int64_t t = 0;
-    for (const Quad& q : quads) {
-      const int64_t u = t % (2 * (int64_t)world_size);
-      const int r = (int)(u < world_size ? u : 2 * (int64_t)world_size - 1 - u);
-      per_rank[r] += 4;
-      if (r == rank) {
-        const int32_t is[2] = {q.i1, q.i2}, js[2] = {q.j1, q.j2};
-        for (int b = 0; b < 2; ++b)
-          for (int a = 0; a < 2; ++a) {
-            p->pairs.push_back(is[a]);
-            p->pairs.push_back(js[b]);
-            const bool redundant = (a == 1 && q.i2 == q.i1) || (b == 1 && q.j2 == q.j1) || (sym && is[a] > js[b]);
-            if (!redundant) {
-              double f, fp, by;
-              work(is[a], js[b], &f, &fp, &by);
-              flops += f, padded += fp, bytes += by;
-            }
-          }
-      }
-      ++t;
-    }
-    p->groups = {0, 0};
-    p->n_first = (int64_t)p->pairs.size() / 2;
-    p->total_pairs = 4 * t;
-    p->max_per_rank = *std::max_element(per_rank.begin(), per_rank.end());
-    p->stats.pairs = (int64_t)p->pairs.size() / 2;
-    p->stats.flops = flops, p->stats.padded_flops = padded, p->stats.bytes = bytes;
-    *out = p;
-    return QK_OK;
-  }
-  {
-    const char* e = std::getenv("QK_PLAN_XCD");
-    if (block_arg <= 0 && !(e && std::atoi(e) == 0)) {
-      int T = 8;
-      if (const char* te = std::getenv("QK_PLAN_TILE")) T = std::max(1, std::min(64, std::atoi(te)));
-      plan_tiled(p, n_sites, nx, x_dims, ny, y_dims, sym, orient, world_size, rank, T);
-      *out = p;
-      return QK_OK;
-    }
-  }
-  std::vector<Item> tile;
-  const int stride = n_sites + 1;
-  int64_t t = 0;  // running index in the global order
-  std::vector<int64_t> per_rank(world_size, 0);
-  std::vector<int32_t> tile_of;  // locality tile of each pair of this rank
-  double flops = 0, padded = 0, bytes = 0, fit_two = 0, fit_narrow = 0;
-  const int nbx = (nx + block - 1) / block, nby = (ny + block - 1) / block;
-  for (int bj = 0; bj < nby; ++bj)
-    for (int bi = 0; bi < nbx; ++bi) {
-      if (sym && bi > bj) continue;
-      tile.clear();
-      for (int j = bj * block; j < std::min(ny, (bj + 1) * block); ++j)
-        for (int i = bi * block; i < std::min(nx, (bi + 1) * block); ++i) {
-          if (sym && i > j) continue;
-          double f, fp, by;
-          int xi = i, yj = j;  // the cheaper order of contraction: which state plays Y (QK_PLAN_ORIENT)
-          if (orient && i != j && fused_cost(n_sites, x_dims + (int64_t)j * stride, y_dims + (int64_t)i * stride) < fused_cost(n_sites, x_dims + (int64_t)i * stride, y_dims + (int64_t)j * stride))
-            xi = j, yj = i;
-          pair_work(n_sites, x_dims + (int64_t)xi * stride, y_dims + (int64_t)yj * stride, &f, &fp, &by);
-          tile.push_back({xi, yj, (float)fp});
-        }
-      std::stable_sort(tile.begin(), tile.end(), [](const Item& u, const Item& v) { return u.cost > v.cost; });
-      for (const Item& it : tile) {
-        // serpentine deal (0..W-1, W-1..0, ...): in a cost-sorted run plain round-robin would hand rank 0 the
-        // heaviest pair of every W (13 % more flops than rank W-1 on cfg4 at W = 8)
-        const int64_t u = t % (2 * (int64_t)world_size);
-        const int r = (int)(u < world_size ? u : 2 * (int64_t)world_size - 1 - u);
-        ++per_rank[r];
-        if (r == rank) {
-          p->pairs.push_back(it.i);
-          p->pairs.push_back(it.j);
-          tile_of.push_back(bj * nbx + bi);
-          double f, fp, by, ft, fn;
-          pair_work(n_sites, x_dims + (int64_t)it.i * stride, y_dims + (int64_t)it.j * stride, &f, &fp, &by, &ft, &fn);
-          flops += f, padded += fp, bytes += by, fit_two += ft, fit_narrow += fn;
-        }
-        ++t;
-      }
-    }
-  // Regroup this rank's share: pairs that share the x state are made contiguous and cut into
-  // groups of at most QK_GROUP (default 4) pairs -- one workgroup sweeps a group in lockstep so
-  // that A_i is read once per group and the per-phase latencies are shared.  Groups are then
-  // ordered by decreasing cost (longest first for the device-side queue) -- inside their locality tile when the plan has
-  // tiles (`block`): the queue then walks the Gram tile by tile.
-  {
-    int G = 4;
-    if (const char* e = std::getenv("QK_GROUP")) G = std::max(1, std::min(4, std::atoi(e)));
-    p->group = G;
-    const int64_t np = (int64_t)p->pairs.size() / 2;
-    std::vector<Item> mine((size_t)np);
-    // Two classes of pairs: a set of states of very different entanglement (the 60-qubit x 6-layer set: largest bond 40 ... 248,
-    // median 78) holds pairs that are best swept by one 12-wave workgroup per CU next to pairs whose sites all fit the
-    // smaller LDS buffer and are best swept two workgroups per CU.  Class-1 pairs (>= QK_PLAN_SPLIT, default 0.75, of their
-    // padded work fits the smaller buffer) are listed behind the others; qk_gram_values may sweep the two runs with the two
-    // shapes of the site-fused kernel.
-    double split = 0.75;
-    if (const char* e = std::getenv("QK_PLAN_SPLIT")) split = std::atof(e);
-    double small_work = 0;
-    for (int64_t q = 0; q < np; ++q) {
-      double f, fp, by, ft;
-      const int i = p->pairs[2 * q], j = p->pairs[2 * q + 1];
-      pair_work(n_sites, x_dims + (int64_t)i * stride, y_dims + (int64_t)j * stride, &f, &fp, &by, &ft);
-      const int cls = (fp > 0 && ft >= split * fp) ? 1 : 0;
-      if (cls) small_work += fp, p->second.pairs += 1, p->second.flops += f, p->second.padded_flops += fp, p->second.bytes += by;
-      mine[(size_t)q] = {i, j, (float)fp, tile_of[(size_t)q], cls};
-    }
-    if (small_work < 0.05 * padded || small_work > 0.95 * padded) {  // (nearly) one class: no split
-      for (Item& it : mine) it.cls = 0;
-      p->second = qk_stats{};
-    }
-    std::stable_sort(mine.begin(), mine.end(), [](const Item& u, const Item& v) {
-      return u.cls != v.cls ? u.cls < v.cls : u.tile != v.tile ? u.tile < v.tile : u.i != v.i ? u.i < v.i : u.cost > v.cost;
-    });
-    struct Grp {
-      int64_t start;
-      int count;
-      double cost;
-      int32_t tile, cls;
-    };
-    std::vector<Grp> grp;
-    for (int64_t q = 0; q < np;) {
-      int c = 1;
-      double cost = mine[(size_t)q].cost;
-      while (c < G && q + c < np && mine[(size_t)(q + c)].i == mine[(size_t)q].i && mine[(size_t)(q + c)].tile == mine[(size_t)q].tile && mine[(size_t)(q + c)].cls == mine[(size_t)q].cls)
-        cost += mine[(size_t)(q + c)].cost, ++c;
-      grp.push_back({q, c, cost, mine[(size_t)q].tile, mine[(size_t)q].cls});
-      q += c;
-    }
-    std::stable_sort(grp.begin(), grp.end(), [](const Grp& u, const Grp& v) { return u.cls != v.cls ? u.cls < v.cls : u.tile != v.tile ? u.tile < v.tile : u.cost > v.cost; });
-    p->pairs.clear();
-    p->n_first = np;
-    for (const Grp& gq : grp) {
-      if (gq.cls == 1 && p->n_first == np) p->n_first = (int64_t)p->pairs.size() / 2;  // where the class-1 run starts
-      p->groups.push_back((int32_t)(p->pairs.size() / 2));
-      p->groups.push_back(gq.count);
-      for (int c = 0; c < gq.count; ++c) {
-        p->pairs.push_back(mine[(size_t)(gq.start + c)].i);
-        p->pairs.push_back(mine[(size_t)(gq.start + c)].j);
-      }
-    }
-  }
-  p->total_pairs = t;
-  p->max_per_rank = *std::max_element(per_rank.begin(), per_rank.end());
-  p->stats.pairs = (int64_t)p->pairs.size() / 2;
-  p->stats.flops = flops, p->stats.padded_flops = padded, p->stats.bytes = bytes;
-  p->fit_two = padded > 0 ? fit_two / padded : 1.0;
-  p->fit_narrow = padded > 0 ? fit_narrow / padded : 1.0;
-  p->nq = 1;  // the flat list: one queue per launch
-  p->edge_k = choose_edge_k(n_sites, x_dims, y_dims, p->pairs);
-  *out = p;
-  return QK_OK;
-}
 
 extern "C" int qk_plan_destroy(qk_plan* plan) {
   if (!plan) return QK_OK;
@@ -646,24 +175,6 @@ extern "C" int qk_plan_destroy(qk_plan* plan) {
   delete plan;
   return QK_OK;
 }
-extern "C" int64_t qk_plan_num_pairs(const qk_plan* p) { return p ? (int64_t)p->pairs.size() / 2 : 0; }
-extern "C" int64_t qk_plan_total_pairs(const qk_plan* p) { return p ? p->total_pairs : 0; }
-extern "C" int64_t qk_plan_max_pairs_per_rank(const qk_plan* p) { return p ? p->max_per_rank : 0; }
-extern "C" const int32_t* qk_plan_pairs(const qk_plan* p) { return p ? p->pairs.data() : nullptr; }
-extern "C" int64_t qk_plan_first_run(const qk_plan* p) { return p ? (p->n_first > 0 ? p->n_first : (int64_t)p->pairs.size() / 2) : 0; }
-extern "C" int32_t qk_plan_edge_sites(const qk_plan* p) { return p ? p->edge_k : 0; }
-extern "C" int qk_plan_queues(const qk_plan* p, int64_t* qstart) {
-  if (!p) return 0;
-  if (qstart)
-    for (int s = 0; s <= QK_NQ_MAX; ++s) qstart[s] = p->nq > 1 ? p->qstart[s] : (s == 0 ? 0 : (int64_t)p->pairs.size() / 2);
-  return p->nq;
-}
-extern "C" int qk_plan_stats(const qk_plan* p, qk_stats* out) {
-  if (!p || !out) return fail(QK_EINVAL, "qk_plan_stats: null argument");
-  *out = p->stats;
-  return QK_OK;
-}
-
 // ----------------------------------------------------------------------------------------
 // small kernels of the product path (the sweep kernels are in qk_ring.h)
 // ----------------------------------------------------------------------------------------
@@ -682,44 +193,68 @@ __global__ void qk_scatter_kernel(const int32_t* __restrict__ pairs, const doubl
   if (mirror) K[(long long)i * ld + j] = v;
 }
 
+// ----------------------------------------------------------------------------------------
+// Derived images of a set (made once per set, on the cold path of its first Gram): both are chains of small complex products and run
+// on the f64 matrix cores, reading the interleaved image like the sweep does.
+// ----------------------------------------------------------------------------------------
+typedef double qk_v2d __attribute__((ext_vector_type(2)));
+
+// One 16 x 16 complex tile  C[m][n] = sum_{k < 4 ks4} P[k][m] Q[k][n]  (3M product).  Element (k, m) of P at P + k pk + m pm, element
+// (k, n) of Q at Q + k qk + n qn (complex elements); the tile comes back in the C/D register layout (register r of lane (q, j) = C[q + 4 r][j]).
+__device__ __forceinline__ void qk_ctile(QkfTile& t, const qk_v2d* __restrict__ P, const long pk, const long pm, const qk_v2d* __restrict__ Q, const long qk, const long qn, const int ks4,
+                                         const int q, const int j) {
+  const qk_v2d* pp = P + q * pk + j * pm;
+  const qk_v2d* qq = Q + q * qk + j * qn;
+  v4d p1 = {0, 0, 0, 0}, p2 = {0, 0, 0, 0}, p3 = {0, 0, 0, 0};
+  qk_v2d a = pp[0], b = qq[0];
+  for (int ks = 0; ks < ks4; ++ks) {
+    const qk_v2d a0 = a, b0 = b;
+    if (ks + 1 < ks4) a = pp[(long)4 * (ks + 1) * pk], b = qq[(long)4 * (ks + 1) * qk];
+    qkf_kstep<false>(p1, p2, p3, a0.x, a0.y, b0.x, b0.y);
+  }
+  t.re = p1 - p2, t.im = p3 - p1 - p2;
+}
+
 // Edge blocks of a set (SweepArgs.edge_k; qk_fused.h): per state the first k sites contracted into L[s][a] (s = the configuration of
 // the first k physical legs, row index built as 2 s + p site by site; a = bond k, padded) and the last k sites into R[s][a] (a = bond
-// n - k).  One workgroup per (state, side) at a time; a step multiplies the block so far by one site tensor (split planes of the
-// set image), ping-pong between two scratch buffers of the workgroup, the last step writes the destination.  Interleaved complex.
-typedef double qk_v2d __attribute__((ext_vector_type(2)));
-__global__ __launch_bounds__(256) void qk_edge_kernel(const double* __restrict__ data, const int32_t* __restrict__ dims, const int64_t* __restrict__ offs, const int n_sites, const int k,
-                                                      const long long n_states, qk_v2d* __restrict__ edge, const long long* __restrict__ edge_offs, qk_v2d* __restrict__ tmp,
-                                                      const long long tmp_elems) {
+// n - k).  One workgroup per (state, side) at a time; a step multiplies the block so far by one site tensor of the interleaved image --
+// out[2 s + p][c] = sum_l in[s][l] A[l][p][c] on the left, A[c][p][l] on the right: 16 x 16 tiles dealt to the workgroup's wavefronts,
+// K up to the TRUE bond --, ping-pong between two scratch buffers of the workgroup, the last step writes the destination.
+__global__ __launch_bounds__(256) void qk_edge_kernel(const qk_v2d* __restrict__ il, const int32_t* __restrict__ dims, const int32_t* __restrict__ dtrue, const int64_t* __restrict__ offs,
+                                                      const int n_sites, const int k, const long long n_states, qk_v2d* __restrict__ edge, const long long* __restrict__ edge_offs,
+                                                      qk_v2d* __restrict__ tmp, const long long tmp_elems) {
   qk_v2d* const t0 = tmp + (long long)blockIdx.x * 2 * tmp_elems;
   qk_v2d* const t1 = t0 + tmp_elems;
-  const int n1 = n_sites + 1;
+  const int n1 = n_sites + 1, lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6, j = lane & 15, q = lane >> 4;
   for (long long t = blockIdx.x; t < 2 * n_states; t += gridDim.x) {
     const long long st = t >> 1;
     const int right = (int)(t & 1);
     const int32_t* d = dims + st * n1;
+    const int32_t* dt = dtrue + st * n1;
     qk_v2d* const dst = edge + edge_offs[t];
-    // the block before the first step: one row, 1 at [0][0] (the boundary bond is 1, padded to 16)
-    for (int e = threadIdx.x; e < 16; e += blockDim.x) t0[e] = (qk_v2d){e == 0 ? 1.0 : 0.0, 0.0};
+    // the block before the first step: one row, 1 at [0][0] (the boundary bond is 1, padded to 16); the other 15 rows of its tile are zero
+    for (int e = threadIdx.x; e < 256; e += blockDim.x) t0[e] = (qk_v2d){e == 0 ? 1.0 : 0.0, 0.0};
     __syncthreads();
     const qk_v2d* in = t0;
     for (int jj = 0; jj < k; ++jj) {
       const int site = right ? n_sites - 1 - jj : jj;
       const int lp = d[site], rp = d[site + 1];  // padded bonds of the site tensor [lp][2][rp]
-      const double* re = data + offs[st * n_sites + site];
-      const double* im = re + (long long)lp * 2 * rp;
+      const qk_v2d* const A = il + (offs[st * n_sites + site] >> 1);
       const int ld_in = right ? rp : lp, ld_out = right ? lp : rp, rows_in = 1 << jj;
+      const int ks4 = ((right ? dt[site + 1] : dt[site]) + 3) >> 2;  // k-steps below the true bond that is summed over
       qk_v2d* const out = (jj + 1 == k) ? dst : (in == t0 ? t1 : t0);
-      for (int e = threadIdx.x; e < 2 * rows_in * ld_out; e += blockDim.x) {
-        const int row = e / ld_out, c = e - row * ld_out, s_ = row >> 1, pp = row & 1;
-        double ar = 0, ai = 0;
-        for (int l = 0; l < ld_in; ++l) {
-          const qk_v2d x = in[(long long)s_ * ld_in + l];
-          // left: A[l][pp][c];  right: A[c][pp][l]
-          const long long idx = right ? ((long long)(c * 2 + pp) * rp + l) : ((long long)(l * 2 + pp) * rp + c);
-          const double tr = re[idx], ti = im[idx];
-          ar += x.x * tr - x.y * ti, ai += x.x * ti + x.y * tr;
+      const int nts = (rows_in + 15) >> 4, ntc = ld_out >> 4;
+      for (int u = wave; u < nts * 2 * ntc; u += nw) {
+        const int tc = u % ntc, pp = (u / ntc) & 1, ts = u / (2 * ntc);
+        QkfTile T;
+        // left: Q[l][c] = A[l][pp][c];  right: Q[l][c] = A[c][pp][l]
+        if (right) qk_ctile(T, in + (long)(ts * 16) * ld_in, 1, ld_in, A + (long)pp * rp + (long)(tc * 16) * 2 * rp, 1, 2 * rp, ks4, q, j);
+        else qk_ctile(T, in + (long)(ts * 16) * ld_in, 1, ld_in, A + (long)pp * rp + tc * 16, 2 * rp, 1, ks4, q, j);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int s_ = ts * 16 + q + 4 * r;
+          if (s_ < rows_in) out[(long)(2 * s_ + pp) * ld_out + tc * 16 + j] = (qk_v2d){T.re[r], T.im[r]};
         }
-        out[e] = (qk_v2d){ar, ai};
       }
       __syncthreads();
       in = out;
@@ -728,40 +263,57 @@ __global__ __launch_bounds__(256) void qk_edge_kernel(const double* __restrict__
 }
 
 // Merged image of a set (SweepArgs.merge_steps; qk_fused.h): step t of state st = the chain's sites s = k + 2 t and s + 1 contracted over
-// the bond between them, M[l][2 p1 + p2][r] = sum_m A_s[l][p1][m] A_{s+1}[m][p2][r] (padded bonds; the padding of the planes is zero,
-// so is M's).  One workgroup per step at a time, a thread per (l, r) with the four physical combinations in registers; reads the
-// split planes, writes interleaved complex.  Once per set: not part of a sweep.
-__global__ __launch_bounds__(256) void qk_merge_kernel(const double* __restrict__ data, const int32_t* __restrict__ dims, const int64_t* __restrict__ offs, const int n_sites, const int k,
-                                                       const int steps, const long long n_states, qk_v2d* __restrict__ out, const int64_t* __restrict__ out_offs) {
-  const int n1 = n_sites + 1;
-  for (long long t = blockIdx.x; t < n_states * steps; t += gridDim.x) {
-    const long long st = t / steps;
-    const int step = (int)(t - st * steps), s_ = k + 2 * step;
+// the bond between them, M[l][2 p1 + p2][r] = sum_m A_s[l][p1][m] A_{s+1}[m][p2][r] (padded bonds; the padding of the image is zero,
+// so is M's).  A UNIT is one 16 x 16 block (tl, tr) of one step with its four physical combinations: the two fragments of A_s and the two
+// of A_{s+1} of a k-step feed four complex products (12 matrix instructions per 4 loads), K up to the true bond between the sites.  Units
+// of all steps and states are numbered through a prefix table (unit_start) and dealt to the wavefronts of the grid, so the launch
+// does not end with the largest state.  Reads and writes interleaved complex.  Once per set: not part of a sweep.
+__global__ __launch_bounds__(256, 2) void qk_merge_kernel(const qk_v2d* __restrict__ il, const int32_t* __restrict__ dims, const int32_t* __restrict__ dtrue, const int64_t* __restrict__ offs,
+                                                          const int n_sites, const int k, const int steps, const long long n_tasks, const long long* __restrict__ unit_start,
+                                                          qk_v2d* __restrict__ out, const int64_t* __restrict__ out_offs) {
+  const int n1 = n_sites + 1, lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6, j = lane & 15, q = lane >> 4;
+  const long long n_units = unit_start[n_tasks];
+  for (long long u = (long long)blockIdx.x * nw + wave; u < n_units; u += (long long)gridDim.x * nw) {
+    long long lo = 0, hi = n_tasks;  // the task of unit u: the last t with unit_start[t] <= u
+    while (hi - lo > 1) {
+      const long long mid = (lo + hi) >> 1;
+      if (unit_start[mid] <= u) lo = mid;
+      else hi = mid;
+    }
+    const long long t = lo, st = t / steps;
+    const int step = (int)(t - st * steps), s_ = k + 2 * step, v = (int)(u - unit_start[t]);
     const int32_t* d = dims + st * n1;
-    qk_v2d* const dst = out + (out_offs[t] >> 1);
-    const int lp = d[s_], mp = d[s_ + 1], rp = d[s_ + 2];
-    const double* re1 = data + offs[st * n_sites + s_];
-    const double* im1 = re1 + (long long)lp * 2 * mp;
-    const double* re2 = data + offs[st * n_sites + s_ + 1];
-    const double* im2 = re2 + (long long)mp * 2 * rp;
-    for (int e = threadIdx.x; e < lp * rp; e += blockDim.x) {
-      const int l = e / rp, r = e - l * rp;
-      double ar[4] = {0, 0, 0, 0}, ai[4] = {0, 0, 0, 0};
-      const double* a0r = re1 + (long long)(2 * l) * mp;  // A_s[l][0][.], [l][1][.] follows at + mp
-      const double* a0i = im1 + (long long)(2 * l) * mp;
-      for (int m = 0; m < mp; ++m) {
-        const double xr[2] = {a0r[m], a0r[mp + m]}, xi[2] = {a0i[m], a0i[mp + m]};
-        const long long o2 = (long long)(2 * m) * rp + r;  // A_{s+1}[m][0][r], [m][1][r] at + rp
-        const double yr[2] = {re2[o2], re2[o2 + rp]}, yi[2] = {im2[o2], im2[o2 + rp]};
+    const int lp = d[s_], mp = d[s_ + 1], rp = d[s_ + 2], ntr = rp >> 4, tl = v / ntr, tr = v - tl * ntr;
+    (void)lp;
+    const int ks4 = (dtrue[st * n1 + s_ + 1] + 3) >> 2;
+    const qk_v2d* const A1 = il + (offs[st * n_sites + s_] >> 1);      // [lp][2][mp]
+    const qk_v2d* const A2 = il + (offs[st * n_sites + s_ + 1] >> 1);  // [mp][2][rp]
+    // lane (q, j) of k-step ks: A1[16 tl + j][p1][4 ks + q], A2[4 ks + q][p2][16 tr + j]
+    const qk_v2d* pa = A1 + ((long)(tl * 16 + j) * 2) * mp + q;
+    const qk_v2d* pb = A2 + ((long)q * 2) * rp + tr * 16 + j;
+    v4d acc[4][3];
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          const int p1 = c >> 1, p2 = c & 1;
-          ar[c] += xr[p1] * yr[p2] - xi[p1] * yi[p2];
-          ai[c] += xr[p1] * yi[p2] + xi[p1] * yr[p2];
-        }
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+      for (int e = 0; e < 3; ++e) acc[c][e] = (v4d){0, 0, 0, 0};
+    qk_v2d a0 = pa[0], a1 = pa[mp], b0 = pb[0], b1 = pb[rp];
+    for (int ks = 0; ks < ks4; ++ks) {
+      const qk_v2d x0 = a0, x1 = a1, y0 = b0, y1 = b1;
+      if (ks + 1 < ks4) {
+        pa += 4, pb += (long)8 * rp;
+        a0 = pa[0], a1 = pa[mp], b0 = pb[0], b1 = pb[rp];
       }
+      qkf_kstep<false>(acc[0][0], acc[0][1], acc[0][2], x0.x, x0.y, y0.x, y0.y);
+      qkf_kstep<false>(acc[1][0], acc[1][1], acc[1][2], x0.x, x0.y, y1.x, y1.y);
+      qkf_kstep<false>(acc[2][0], acc[2][1], acc[2][2], x1.x, x1.y, y0.x, y0.y);
+      qkf_kstep<false>(acc[3][0], acc[3][1], acc[3][2], x1.x, x1.y, y1.x, y1.y);
+    }
+    qk_v2d* const dst = out + (out_offs[t] >> 1);
 #pragma unroll
-      for (int c = 0; c < 4; ++c) dst[(long long)(4 * l + c) * rp + r] = (qk_v2d){ar[c], ai[c]};
+    for (int c = 0; c < 4; ++c) {
+      const v4d re = acc[c][0] - acc[c][1], im = acc[c][2] - acc[c][0] - acc[c][1];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) dst[(long)(4 * (tl * 16 + q + 4 * r) + c) * rp + tr * 16 + j] = (qk_v2d){re[r], im[r]};
     }
   }
 }
@@ -830,6 +382,7 @@ static int ctx_init(qk_ctx* c, int device_id, int num_cus) {
   HIP_TRY(hipEventCreate(&c->ev0));
   HIP_TRY(hipEventCreate(&c->ev1));
   HIP_TRY(hipEventCreate(&c->ev_mid));
+  HIP_TRY(hipEventCreate(&c->ev_d));
   HIP_TRY(hipMalloc(&c->counter, (QK_NQ_MAX * QK_QSTRIDE + 8) * sizeof(unsigned long long)));  // queue heads (8 per launch of a split sweep), tail clocks
   HIP_TRY(hipMalloc(&c->prof, 8 * sizeof(unsigned long long)));
   HIP_TRY(hipMemset(c->prof, 0, 8 * sizeof(unsigned long long)));
@@ -871,11 +424,13 @@ extern "C" int qk_ctx_destroy(qk_ctx* c) {
   if (c->scratch) (void)hipFree(c->scratch);
   if (c->build_arena) (void)hipFree(c->build_arena);
   if (c->build_work) (void)hipFree(c->build_work);
+  if (c->derive_tmp) (void)hipFree(c->derive_tmp);
   if (c->counter) (void)hipFree(c->counter);
   if (c->prof) (void)hipFree(c->prof);
   if (c->ev0) (void)hipEventDestroy(c->ev0);
   if (c->ev1) (void)hipEventDestroy(c->ev1);
   if (c->ev_mid) (void)hipEventDestroy(c->ev_mid);
+  if (c->ev_d) (void)hipEventDestroy(c->ev_d);
   if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
   delete c;
   return QK_OK;
@@ -888,6 +443,8 @@ extern "C" int qk_ctx_trim(qk_ctx* c) {
   if (c->scratch) (void)hipFree(c->scratch);
   if (c->build_arena) (void)hipFree(c->build_arena);
   if (c->build_work) (void)hipFree(c->build_work);
+  if (c->derive_tmp) (void)hipFree(c->derive_tmp);
+  c->derive_tmp = nullptr, c->derive_tmp_bytes = 0;
   c->scratch = nullptr, c->scratch_bytes = 0;
   c->build_arena = nullptr, c->build_arena_bytes = 0;
   c->build_work = nullptr, c->build_work_bytes = 0;
@@ -1120,14 +677,18 @@ static int ensure_interleaved(qk_ctx* c, qk_mps_set* m) {
   return QK_OK;
 }
 
-// the edge blocks of a set for `k` sites at either end (made once per set and k; fp64 sets)
+// the edge blocks of a set for `k` sites at either end (made once per set and k; fp64 sets; needs the interleaved image).
+// Asynchronous: the kernel is enqueued on the context's stream and nothing waits for it here (the staging tables live in the set,
+// the workgroups' scratch in the context), so that a caller with several devices can enqueue all of them before any of them is done.
 static int ensure_edges(qk_ctx* c, qk_mps_set* m, const int k) {
   if (k <= 0 || (m->d_edge && m->edge_k == k)) return QK_OK;
+  if (m->d_edge || m->d_edge_offs) HIP_TRY(hipStreamSynchronize(c->stream));  // (a plan with another k: the old blocks may still be read)
   if (m->d_edge) (void)hipFree(m->d_edge);
   if (m->d_edge_offs) (void)hipFree(m->d_edge_offs);
   m->d_edge = nullptr, m->d_edge_offs = nullptr, m->edge_k = 0, m->edge_bytes = 0;
   const int n = m->n_sites, stride = n + 1;
-  std::vector<long long> offs((size_t)m->n_states * 2);
+  std::vector<long long>& offs = m->h_edge_offs;
+  offs.assign((size_t)m->n_states * 2, 0);
   long long total = 0;
   int maxld = 16;
   for (int s_ = 0; s_ < m->n_states; ++s_) {
@@ -1138,16 +699,23 @@ static int ensure_edges(qk_ctx* c, qk_mps_set* m, const int k) {
     total += (long long)(1 << k) * pad16(d[n - k]);
     for (int jj = 0; jj <= k; ++jj) maxld = std::max(maxld, std::max(pad16(d[jj]), pad16(d[n - jj])));
   }
-  const long long tmp_elems = (long long)(1 << (k - 1)) * maxld;  // the largest intermediate block
+  const long long tmp_elems = (long long)std::max(1 << (k - 1), 16) * maxld;  // the largest intermediate block (at least one 16-row tile)
   const int grid = (int)std::min<long long>(2ll * m->n_states, 4ll * c->num_cus);
-  DevBuf eb, ob, tb;
+  const size_t tmp_bytes = (size_t)grid * 2 * tmp_elems * 2 * sizeof(double);
+  if (tmp_bytes > c->derive_tmp_bytes) {
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (c->derive_tmp) (void)hipFree(c->derive_tmp);
+    c->derive_tmp = nullptr, c->derive_tmp_bytes = 0;
+    HIP_TRY(hipMalloc(&c->derive_tmp, tmp_bytes));
+    c->derive_tmp_bytes = tmp_bytes;
+  }
+  DevBuf eb, ob;
   HIP_TRY(eb.alloc((size_t)total * 2 * sizeof(double)));
   HIP_TRY(ob.alloc(offs.size() * sizeof(long long)));
-  HIP_TRY(tb.alloc((size_t)grid * 2 * tmp_elems * 2 * sizeof(double)));
   HIP_TRY(hipMemcpyAsync(ob.p, offs.data(), offs.size() * sizeof(long long), hipMemcpyHostToDevice, c->stream));
-  qk_edge_kernel<<<dim3(grid), dim3(256), 0, c->stream>>>(m->d_data, m->d_dims, m->d_offs, n, k, m->n_states, eb.as<qk_v2d>(), ob.as<long long>(), tb.as<qk_v2d>(), tmp_elems);
+  qk_edge_kernel<<<dim3(grid), dim3(256), 0, c->stream>>>(reinterpret_cast<const qk_v2d*>(m->d_il), m->d_dims, m->d_true, m->d_offs, n, k, m->n_states, eb.as<qk_v2d>(), ob.as<long long>(),
+                                                          static_cast<qk_v2d*>(c->derive_tmp), tmp_elems);
   HIP_TRY(hipGetLastError());
-  HIP_TRY(hipStreamSynchronize(c->stream));  // (the scratch goes out of scope; once per set)
   m->d_edge = eb.as<double>(), m->d_edge_offs = ob.as<long long>();
   eb.p = nullptr, ob.p = nullptr;
   m->edge_k = k, m->edge_bytes = total * 2 * (long long)sizeof(double);
@@ -1157,35 +725,47 @@ static int ensure_edges(qk_ctx* c, qk_mps_set* m, const int k) {
 static void free_merged(qk_mps_set* m) {
   if (m->d_mg) (void)hipFree(m->d_mg);
   if (m->d_mg_offs) (void)hipFree(m->d_mg_offs);
-  m->d_mg = nullptr, m->d_mg_offs = nullptr, m->mg_k = -1, m->mg_steps = 0, m->mg_bytes = 0;
+  if (m->d_mg_units) (void)hipFree(m->d_mg_units);
+  m->d_mg = nullptr, m->d_mg_offs = nullptr, m->d_mg_units = nullptr, m->mg_k = -1, m->mg_steps = 0, m->mg_bytes = 0;
 }
 
-// the merged image of a set for a chain that starts `k` sites in (made once per set and k; fp64 sets)
+// the merged image of a set for a chain that starts `k` sites in (made once per set and k; fp64 sets; needs the interleaved image).
+// Asynchronous like ensure_edges.
 static int ensure_merged(qk_ctx* c, qk_mps_set* m, const int k) {
   if (m->d_mg && m->mg_k == k) return QK_OK;
+  if (m->d_mg) HIP_TRY(hipStreamSynchronize(c->stream));
   free_merged(m);
   const int n = m->n_sites, stride = n + 1, steps = (n - 2 * k) / 2;
   if (steps < 1) return fail(QK_EINVAL, "ensure_merged: a chain of %d sites", n - 2 * k);
-  std::vector<int64_t> mo((size_t)m->n_states * steps);
-  long long total = 0;  // complex elements
+  std::vector<int64_t>& mo = m->h_mg_offs;
+  std::vector<long long>& us = m->h_mg_units;
+  mo.assign((size_t)m->n_states * steps, 0);
+  us.assign((size_t)m->n_states * steps + 1, 0);
+  long long total = 0, units = 0;  // complex elements; 16 x 16 blocks (with their four physical combinations)
   for (int s_ = 0; s_ < m->n_states; ++s_) {
     const int32_t* d = m->dims_true.data() + (size_t)s_ * stride;
     for (int t = 0; t < steps; ++t) {
+      const long long lp = pad16(d[k + 2 * t]), rp = pad16(d[k + 2 * t + 2]);
       mo[(size_t)s_ * steps + t] = 2 * total;
-      total += 4ll * pad16(d[k + 2 * t]) * pad16(d[k + 2 * t + 2]);
+      us[(size_t)s_ * steps + t] = units;
+      total += 4ll * lp * rp;
+      units += (lp / 16) * (rp / 16);
     }
   }
-  DevBuf ib, ob;
+  us.back() = units;
+  DevBuf ib, ob, ub;
   HIP_TRY(ib.alloc((size_t)total * 2 * sizeof(double)));
   HIP_TRY(ob.alloc(mo.size() * sizeof(int64_t)));
+  HIP_TRY(ub.alloc(us.size() * sizeof(long long)));
   HIP_TRY(hipMemcpyAsync(ob.p, mo.data(), mo.size() * sizeof(int64_t), hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(hipMemcpyAsync(ub.p, us.data(), us.size() * sizeof(long long), hipMemcpyHostToDevice, c->stream));
   const long long tasks = (long long)m->n_states * steps;
-  qk_merge_kernel<<<dim3((unsigned)std::min<long long>(tasks, 16ll * c->num_cus)), dim3(256), 0, c->stream>>>(m->d_data, m->d_dims, m->d_offs, n, k, steps, m->n_states, ib.as<qk_v2d>(),
-                                                                                                                  ob.as<int64_t>());
+  const unsigned grid = (unsigned)std::min<long long>((units + 3) / 4, 4ll * c->num_cus);  // 4 wavefronts per workgroup, two workgroups per SIMD row
+  qk_merge_kernel<<<dim3(grid), dim3(256), 0, c->stream>>>(reinterpret_cast<const qk_v2d*>(m->d_il), m->d_dims, m->d_true, m->d_offs, n, k, steps, tasks, ub.as<long long>(), ib.as<qk_v2d>(),
+                                                          ob.as<int64_t>());
   HIP_TRY(hipGetLastError());
-  HIP_TRY(hipStreamSynchronize(c->stream));  // (the host table goes out of scope; once per set)
-  m->d_mg = ib.as<double>(), m->d_mg_offs = ob.as<int64_t>();
-  ib.p = ob.p = nullptr;
+  m->d_mg = ib.as<double>(), m->d_mg_offs = ob.as<int64_t>(), m->d_mg_units = ub.as<long long>();
+  ib.p = ob.p = ub.p = nullptr;
   m->mg_k = k, m->mg_steps = steps, m->mg_bytes = total * 2 * (long long)sizeof(double);
   return QK_OK;
 }
@@ -1297,6 +877,7 @@ extern "C" int qk_gram_values(qk_ctx* c, const qk_mps_set* xs, const qk_mps_set*
   if (const char* v = std::getenv("QK_DEBUG_FLAGS")) a.debug_flags = std::atoi(v);
   if (const char* v = std::getenv("QK_PRIO")) a.prio_mode = std::atoi(v);
 #endif
+  HIP_TRY(hipEventRecord(c->ev_d, c->stream));
   HIP_TRY(hipMemsetAsync(c->counter, 0, (QK_NQ_MAX * QK_QSTRIDE + 8) * sizeof(unsigned long long), c->stream));
   HIP_TRY(hipMemsetAsync(tail, 0xFF, 4 * sizeof(unsigned long long), c->stream));  // the four minima
   c->last.queues = 1, c->last.tail_frac = c->last.second_tail_frac = 0;
@@ -1348,16 +929,22 @@ extern "C" int qk_gram_values(qk_ctx* c, const qk_mps_set* xs, const qk_mps_set*
       if (rc_il != QK_OK) return rc_il;
     }
     a.xdata = xs->d_il, a.ydata = ys->d_il;
-    if (plan->edge_k > 0) {  // the ends of the chain from the sets' edge blocks (chosen by the planner)
+    // the ends of the chain from the sets' edge blocks: k chosen by the planner -- unless a set already holds blocks for another k
+    // (made for an earlier plan, e.g. the training Gram before the test Gram on the same X): any k gives the same overlaps and the
+    // model's choices lie within 0.5 % of each other, so the set keeps the k of its first use instead of being rebuilt per call
+    int ek = plan->edge_k;
+    if (ek > 0) {
+      if (xs->edge_k > 0 && (ys == xs || ys->edge_k == 0 || ys->edge_k == xs->edge_k)) ek = xs->edge_k;
+      else if (xs->edge_k == 0 && ys->edge_k > 0) ek = ys->edge_k;
       for (const qk_mps_set* m : {xs, ys}) {
-        const int rc_e = ensure_edges(c, const_cast<qk_mps_set*>(m), plan->edge_k);
+        const int rc_e = ensure_edges(c, const_cast<qk_mps_set*>(m), ek);
         if (rc_e != QK_OK) return rc_e;
       }
-      a.xedge = xs->d_edge, a.xedge_offs = xs->d_edge_offs, a.yedge = ys->d_edge, a.yedge_offs = ys->d_edge_offs, a.edge_k = plan->edge_k;
+      a.xedge = xs->d_edge, a.xedge_offs = xs->d_edge_offs, a.yedge = ys->d_edge, a.yedge_offs = ys->d_edge_offs, a.edge_k = ek;
     }
-    if (c->merge_sites && xs->n_sites - 2 * plan->edge_k >= 2) {  // the chain's sites contracted in twos: a workgroup picks per pair and step
+    if (c->merge_sites && xs->n_sites - 2 * ek >= 2) {  // the chain's sites contracted in twos: a workgroup picks per pair and step
       for (const qk_mps_set* m : {xs, ys}) {
-        const int rc_m = ensure_merged(c, const_cast<qk_mps_set*>(m), plan->edge_k);
+        const int rc_m = ensure_merged(c, const_cast<qk_mps_set*>(m), ek);
         if (rc_m != QK_OK) return rc_m;
       }
       a.xmg = xs->d_mg, a.xmg_offs = xs->d_mg_offs, a.ymg = ys->d_mg, a.ymg_offs = ys->d_mg_offs, a.merge_steps = xs->mg_steps;
@@ -1502,6 +1089,8 @@ extern "C" int qk_get_stats(qk_ctx* c, qk_stats* out) {
     float ms = 0;
     HIP_TRY(hipEventElapsedTime(&ms, c->ev0, c->ev1));
     c->last.kernel_ms = ms;
+    HIP_TRY(hipEventElapsedTime(&ms, c->ev_d, c->ev0));
+    c->last.derive_ms = ms;  // device time ahead of the sweep: the derived images of the sets (interleaved, edge blocks, merged steps) on their first Gram
     if (c->tail_pending) {  // device clocks of the launch(es): share of the duration during which the chip was draining
       unsigned long long t[8];
       HIP_TRY(hipMemcpy(t, c->counter + QK_NQ_MAX * QK_QSTRIDE, sizeof t, hipMemcpyDeviceToHost));

@@ -154,6 +154,6 @@ def exchange_sets(comm, ctx, local, lo: int, total: int, force_collective: bool 
             parts = [joined_buf]
         else:
             parts = comm_allgather(comm, mine)
-        joined = np.concatenate(parts)
+        joined = parts[0] if len(parts) == 1 else np.concatenate(parts)  # (one part: already the joined buffer -- no second copy of a multi-GB image)
         full = ctx.set_from_packed(dims_all, offs_all, joined.ctypes.data, joined.shape[0])
     return full, time.perf_counter() - t0

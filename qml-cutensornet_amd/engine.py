@@ -8,6 +8,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import weakref
 from contextlib import contextmanager
 
 import numpy as np
@@ -45,6 +46,7 @@ class QkStats(C.Structure):
         ("queues", C.c_int32),
         ("tail_frac", C.c_double),
         ("second_tail_frac", C.c_double),
+        ("derive_ms", C.c_double),
     ]
 
     def as_dict(self):
@@ -84,6 +86,8 @@ _SIGNATURES = [
     ("qk_plan_first_run", C.c_int64, [_P]),
     ("qk_plan_queues", C.c_int, [_P, _P]),
     ("qk_plan_edge_sites", C.c_int32, [_P]),
+    ("qk_plan_create_all", C.c_int, [C.c_int32, C.c_int32, _P, C.c_int32, _P, C.c_uint32, C.c_int32, _P]),
+    ("qk_plan_cost", C.c_int, [_P, C.POINTER(C.c_double), C.POINTER(C.c_int32), C.POINTER(C.c_double)]),
     ("qk_gram_values", C.c_int, [_P, _P, _P, _P, _P, _P]),
     ("qk_gram_values_host", C.c_int, [_P, _P, _P, _P, _P, _P]),
     ("qk_scatter", C.c_int, [_P, _P, _P, C.c_int64, _P, C.c_int64, C.c_int32]),
@@ -230,6 +234,25 @@ class Plan:
         self._h = h
         self.world_size, self.rank, self.quads = world_size, rank, bool(quads)
 
+    @classmethod
+    def create_all(cls, x_dims, y_dims=None, world_size=1):
+        """The plans of all ``world_size`` ranks from ONE cost pass (``qk_plan_create_all``): equal to ``[Plan(x_dims, y_dims,
+        world_size, r) for r in range(world_size)]`` at a fraction of the host time."""
+        xd = np.ascontiguousarray(x_dims, dtype=np.int32)
+        sym = y_dims is None
+        yd = None if sym else np.ascontiguousarray(y_dims, dtype=np.int32)
+        orient = sym and os.environ.get("QK_PLAN_ORIENT", "1") != "0"
+        out = (_P * int(world_size))()
+        _check(lib().qk_plan_create_all(xd.shape[1] - 1, xd.shape[0], xd.ctypes.data, xd.shape[0] if sym else yd.shape[0], None if sym else yd.ctypes.data,
+                                        (QK_PLAN_SYMMETRIC if sym else 0) | (QK_PLAN_ORIENT if orient else 0), int(world_size), out), "qk_plan_create_all")
+        plans = []
+        for r in range(int(world_size)):
+            p = cls.__new__(cls)
+            p.symmetric, p.nx, p.ny = sym, xd.shape[0], xd.shape[0] if sym else yd.shape[0]
+            p.orient, p._h, p.world_size, p.rank, p.quads = orient, _P(out[r]), int(world_size), r, False
+            plans.append(p)
+        return plans
+
     @property
     def handle(self):
         return self._h
@@ -258,6 +281,12 @@ class Plan:
     def first_run(self) -> int:
         """Pairs [first_run, num_pairs) are the run the site-fused sweep takes with its two-workgroups-per-CU shape."""
         return int(lib().qk_plan_first_run(self._h))
+
+    def cost(self) -> dict:
+        """Host cost of making this plan and the tile-reuse lower bound on its bytes (qk_plan_cost)."""
+        ms, th, tr = C.c_double(0), C.c_int32(0), C.c_double(0)
+        _check(lib().qk_plan_cost(self._h, C.byref(ms), C.byref(th), C.byref(tr)), "qk_plan_cost")
+        return {"plan_ms": ms.value, "threads": int(th.value), "tile_reuse_bytes": tr.value}
 
     @property
     def edge_sites(self) -> int:
@@ -292,6 +321,7 @@ class MpsSet:
 
     def __init__(self, ctx, handle, dims):
         self.ctx, self._h, self.dims = ctx, handle, dims
+        ctx._adopt(self)  # the context closes the sets that are still alive before it goes (their handles point into it)
 
     @property
     def handle(self):
@@ -357,6 +387,18 @@ class Context:
         h = _P()
         _check(lib().qk_ctx_create(int(device_id), C.byref(h)), "qk_ctx_create")
         self._h, self.device_id = h, int(device_id)
+        self._sets = weakref.WeakSet()
+
+    def _adopt(self, mps_set):
+        if not hasattr(self, "_sets"):
+            self._sets = weakref.WeakSet()
+        self._sets.add(mps_set)
+
+    def _close_sets(self):
+        """Destroy every MpsSet made on this context that is still alive: ``qk_mps_set_destroy`` dereferences the set's context,
+        so a set must never outlive it (a later ``close()`` / ``__del__`` of such a set is then a no-op)."""
+        for s in list(getattr(self, "_sets", ())):
+            s.close()
 
     @property
     def handle(self):
@@ -611,6 +653,7 @@ class Context:
 
     def close(self):
         if self._h:
+            self._close_sets()
             if not getattr(self, "_borrowed", False):  # a communicator's contexts die with the communicator
                 lib().qk_ctx_destroy(self._h)
             self._h = None
@@ -686,7 +729,8 @@ class Comm:
 
     def close(self):
         if self._h:
-            for c in self._ctx:
+            for c in self._ctx:  # sets made on the communicator's contexts (uploads, all-gathered sets) go first: their handles point
+                c._close_sets()  # into contexts that qk_comm_destroy deletes
                 c._h = None
             lib().qk_comm_destroy(self._h)
             self._h = None

@@ -326,6 +326,9 @@ def build_kernel_matrix(mpi_comm, ansatz, X, Y=None, info_file=None, truncation_
         _say(is_root, "\nContracting the MPS of the circuits from the Y dataset...")
         y_lo, y_local, y_secs, y_fid = _simulate_share(ansatz, Y, rank, n_procs, fidelity, is_root, "Y", device_id, host_workers)
     sim_secs = x_secs + y_secs
+    # the device builder keeps its per-workgroup arena and workspace on the context (tens of GB at large bond caps): they go back before
+    # the exchange and the sweep need the memory (several ranks may share one GPU: device = rank % n_devices, ref :152)
+    ctx.trim()
 
     # every rank gets the whole set: the packed device images of the shares, one all-gather (ref :341-352, 415-419)
     xset, gather_secs = exchange_sets(mpi_comm, ctx, x_local, x_lo, len(X))

@@ -57,6 +57,16 @@ class GramJob:
         self.my_vals = torch.zeros(self.maxp, dtype=torch.float64, device=dev)
         self.all_vals = torch.zeros(self.world * self.maxp, dtype=torch.float64, device=dev) if self.collective else self.my_vals
         self.K = torch.zeros((self.ny, self.nx), dtype=torch.float64, device=dev)
+        self._ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) if self.collective else None
+        self._recorded = False
+
+    def allgather_ms(self) -> float:
+        """Time of the last enqueue's all-gather of the packed values on its stream (it starts when this rank's sweep has ended, so it
+        includes waiting for the slowest rank); 0 without a collective.  Synchronises on the second event."""
+        if self._ev is None or not self._recorded:
+            return 0.0
+        self._ev[1].synchronize()
+        return float(self._ev[0].elapsed_time(self._ev[1]))
 
     def enqueue(self) -> torch.Tensor:
         """Enqueue one full Gram on torch's current stream; returns the device matrix (async)."""
@@ -66,11 +76,14 @@ class GramJob:
         if self.collective:
             import torch.distributed as dist
 
+            self._ev[0].record(stream)
             if dist.get_backend(self.group) == "nccl":  # RCCL over xGMI: the one collective of the path
                 dist.all_gather_into_tensor(self.all_vals, self.my_vals, group=self.group)
             else:  # gloo (tests, several ranks on one GPU): same result through the list form
                 parts = list(self.all_vals.view(self.world, self.maxp).unbind(0))
                 dist.all_gather(parts, self.my_vals, group=self.group)
+            self._ev[1].record(stream)
+            self._recorded = True
         self.ctx.scatter(self.all_pairs.data_ptr(), self.all_vals.data_ptr(), self.all_pairs.shape[0],
                          self.K.data_ptr(), self.nx, self.symmetric)
         return self.K

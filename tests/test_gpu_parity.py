@@ -3,6 +3,8 @@
 Tolerance: the north star asks overlaps to match the CPU backend to 1e-10 (fp64); both sides
 see the same tensors here, so the bound asserted is 1e-11 on |z| <= 1 quantities.
 """
+import ctypes as C
+
 import numpy as np
 import pytest
 
@@ -471,8 +473,23 @@ def test_c_abi_communicator_sharded_gram(gpu_ctx):
             comm.allgather_sets([share], [0], len(xs) + 1)
         with pytest.raises(engine.QkError):
             comm.allgather_sets([gpu_ctx.upload(xs)], [0], len(xs))  # a set of another context
-        for m in (share, full[0], ysets[0]):
-            m.close()
+        # a destroyed set whose address may come back with other bonds must not meet the cached plan of the old one (the job is keyed
+        # on the sets' uids as well as on their addresses): same communicator, new sets with different bonds, right answers
+        ysets[0].close()
+        zs = [Q.random_mps(n, _ragged_profile(rng, n, c), rng) for c in (100, 20, 61)]
+        zsets = [c0.upload(zs)]
+        Kxz = comm.gram(full, zsets)
+        assert np.abs(Kxz - R.gram_from_mps([m.tensors for m in xs], [m.tensors for m in zs])).max() < TOL
+        with pytest.raises(engine.QkError, match="NULL"):  # a ysets array holding a NULL is rejected, not dereferenced
+            L = engine.lib()
+            xs_h = (C.c_void_p * 1)(full[0].handle)
+            ys_h = (C.c_void_p * 1)(None)
+            out = np.zeros((3, len(xs)))
+            engine._check(L.qk_gram_sharded(comm._h, xs_h, ys_h, out.ctypes.data, len(xs)), "qk_gram_sharded")
+        leaked = (share, full[0], zsets[0])  # NOT closed by hand: the communicator closes what lives on its contexts before it goes
+    for m in leaked:
+        assert m.handle is None
+        m.close()  # a no-op now (no use-after-free of the destroyed contexts)
     with pytest.raises(engine.QkError):
         engine.Comm(device_ids=[0, 0])  # one rank per GPU
 

@@ -599,3 +599,90 @@ def test_max_bond_against_published_aggregate(built):
         avg[d] = float(mx.mean())
     assert 10.25 / 2 <= avg[2] <= 10.25 * 2
     assert avg[4] > avg[2] and avg[4] >= 29.375 / 2
+
+
+def _scalar_pair_model(a, b, cap_two=4608, cap_fit=3072):
+    """The work model of one pair, restated literally (qk_planner.cpp pair_work / fused_cost): x = a, y = b."""
+    pad = lambda v: (int(v) + 15) // 16 * 16
+    f = fp = ft = fn = by = c = 0.0
+    for k in range(len(a) - 1):
+        a0, a1, b0, b1 = float(a[k]), float(a[k + 1]), float(b[k]), float(b[k + 1])
+        f += 8 * min(a0 * b0 * 2 * b1 + 2 * a0 * a1 * b1, a0 * b0 * 2 * a1 + 2 * b0 * a1 * b1)
+        A0, A1, B0, B1 = pad(a0), pad(a1), pad(b0), pad(b1)
+        w = 8 * (A0 * B0 * 2 * B1 + 2 * A0 * A1 * B1)
+        fp += w
+        ft += w if (A0 * B0 <= cap_two and A1 * B1 <= cap_two) else 0
+        fn += w if (A0 * B0 <= cap_fit and A1 * B1 <= cap_fit) else 0
+        by += 32.0 * (a0 * a1 + b0 * b1)
+        c += 6 * (A0 // 16) * (B1 // 16) * ((int(b0) + 3) // 4) + 6 * (B1 // 16) * (A1 // 16) * ((int(a0) + 3) // 4)
+    return f, fp, by + 8, c
+
+
+@pytest.mark.parametrize("symmetric", [True, False])
+def test_vectorised_planner_matches_the_scalar_work_model(built, symmetric):
+    """The planner prices pairs with SIMD sums over per-state site vectors on several threads (qk_planner.cpp): the share's
+    algorithmic flops, padded flops and bytes equal the literal per-pair model summed over the plan's pairs EXACTLY (sums of
+    integers held in doubles), every pair of a symmetric plan is listed in the cheaper order, and the tile-reuse byte bound lies
+    between one read per state and the no-reuse figure."""
+    from qml_cutensornet_amd import engine
+
+    rng = np.random.default_rng(23)
+    nx, ny, n = 61, 37, 19
+    xd = np.ones((nx, n + 1), dtype=np.int32)
+    yd = np.ones((ny, n + 1), dtype=np.int32)
+    xd[:, 1:-1] = rng.lognormal(3.7, 0.8, size=(nx, n - 1)).astype(np.int32).clip(1, 250)
+    yd[:, 1:-1] = rng.lognormal(3.2, 0.8, size=(ny, n - 1)).astype(np.int32).clip(1, 250)
+    for world in (1, 3):
+        tot = 0
+        for r in range(world):
+            p = engine.Plan(xd, None if symmetric else yd, world, r)
+            st, pairs, cost = p.stats(), p.pairs(), p.cost()
+            f = fp = by = 0.0
+            for i, j in pairs:
+                a, b = xd[i], (xd if symmetric else yd)[j]
+                fi, fpi, byi, c_ij = _scalar_pair_model(a, b)
+                f, fp, by = f + fi, fp + fpi, by + byi
+                if symmetric and i != j:
+                    assert c_ij <= _scalar_pair_model(b, a)[3], (i, j)
+            assert (st["flops"], st["padded_flops"], st["bytes"]) == (f, fp, by)
+            assert cost["plan_ms"] > 0 and cost["threads"] >= 1
+            states = set(pairs[:, 0]) | set(pairs[:, 1]) if symmetric else None
+            once = sum(32.0 * (xd[s, :-1].astype(float) * xd[s, 1:]).sum() for s in states) if symmetric else 0.0
+            assert once <= cost["tile_reuse_bytes"] <= st["bytes"]
+            tot += len(pairs)
+            p.close()
+        assert tot == (nx * (nx + 1) // 2 if symmetric else nx * ny)
+
+
+@pytest.mark.parametrize("symmetric", [True, False])
+def test_plan_is_independent_of_the_thread_count_and_create_all_equals_create(built, monkeypatch, symmetric):
+    """Same pair lists, queues and work figures with 1, 3 and 7 planner threads; ``qk_plan_create_all`` (one cost pass for all
+    ranks of a one-process communicator) returns exactly the plans of ``world`` calls of ``qk_plan_create``."""
+    from qml_cutensornet_amd import engine
+
+    rng = np.random.default_rng(5)
+    nx, ny, n = 83, 40, 23
+    xd = np.ones((nx, n + 1), dtype=np.int32)
+    yd = np.ones((ny, n + 1), dtype=np.int32)
+    xd[:, 1:-1] = rng.lognormal(3.6, 0.9, size=(nx, n - 1)).astype(np.int32).clip(1, 250)
+    yd[:, 1:-1] = rng.lognormal(3.0, 0.9, size=(ny, n - 1)).astype(np.int32).clip(1, 250)
+    world = 4
+
+    def snapshot(p):
+        return p.pairs().tobytes(), tuple(p.queues()[1]), p.first_run, p.edge_sites, tuple(sorted(p.stats().items())), p.cost()["tile_reuse_bytes"], p.max_pairs_per_rank
+
+    ref = None
+    for threads in ("1", "3", "7"):
+        monkeypatch.setenv("QK_PLAN_THREADS", threads)
+        snaps = []
+        for r in range(world):
+            p = engine.Plan(xd, None if symmetric else yd, world, r)
+            snaps.append(snapshot(p))
+            p.close()
+        if ref is None:
+            ref = snaps
+        assert snaps == ref, threads
+    plans = engine.Plan.create_all(xd, None if symmetric else yd, world)
+    assert [snapshot(p) for p in plans] == ref
+    for p in plans:
+        p.close()
