@@ -94,13 +94,17 @@ typedef struct qk_stats {
 #define QK_KERNEL_NONE 0
 #define QK_KERNEL_WAVE 1    /* qk_sweep_wave_kernel: one pair per wavefront, bonds <= 16, fp64           */
 #define QK_KERNEL_SMALL 2   /* qk_sweep_small_kernel: X, T in LDS, bonds <= 32                            */
-#define QK_KERNEL_FUSED1 3  /* qk_sweep_fused_kernel<12, 2, 8192, 3>: site-fused sweep, one workgroup per CU, single tiles (QK_FUSED_DUAL=0) */
-#define QK_KERNEL_FUSED2 4  /* qk_sweep_fused_kernel<8, 1, 4608, 4>: site-fused sweep, two workgroups per CU */
+#define QK_KERNEL_FUSED1 3  /* qk_sweep_fused_kernel<12, 2, 8192, 3, false>: site-fused sweep, one workgroup per CU, single tiles (QK_FUSED_DUAL=0) */
+#define QK_KERNEL_FUSED2 4  /* qk_sweep_fused_kernel<8, 1, 4608, 4, false>: site-fused sweep, two workgroups per CU */
 #define QK_KERNEL_RING 5    /* qk_sweep_ring_kernel: X, T in an L2-resident scratch                       */
 #define QK_KERNEL_LAB 6     /* an experimental kernel (libqklab.so only)                                  */
 #define QK_KERNEL_WAVE2 7   /* qk_sweep_wave2_kernel<3, double | float>: one pair per wavefront, bonds <= 32 (2 x 2 tiles), fp64 arithmetic on a complex128 or complex64 image */
 #define QK_KERNEL_WAVE2_PLAIN 9 /* qk_sweep_wave2_kernel<0, double>: the same with plain loads instead of the LDS-DMA ring (QK_WAVE2=2) */
-#define QK_KERNEL_FUSED_DUAL 8 /* qk_sweep_fused_dual_kernel<12, 8192, 3>: site-fused sweep, one workgroup per CU, pairs of tiles per wave (the default form of that shape) */
+#define QK_KERNEL_FUSED_DUAL 8 /* qk_sweep_fused_dual_kernel<12, 8192, 3, false>: site-fused sweep, one workgroup per CU, pairs of tiles per wave (the default form of that shape) */
+/* the DET forms of the three site-fused shapes (QK_DETERMINISTIC=1: contributions to X' added in a fixed order -- bit-reproducible Grams) */
+#define QK_KERNEL_FUSED_DUAL_DET 10
+#define QK_KERNEL_FUSED2_DET 11
+#define QK_KERNEL_FUSED1_DET 12
 /* the kernel's name as rocprofv3 prints it (without the "void " and the argument list) */
 const char* qk_kernel_name(int32_t kernel, int32_t precision);
 

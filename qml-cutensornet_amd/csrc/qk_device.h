@@ -50,7 +50,9 @@ struct SweepArgs {
   const int64_t* xmg_offs;
   const int64_t* ymg_offs;
   int merge_steps;
+  int turn_ints;  // the DET forms of the site-fused kernels: turn counters per set = blocks of b' x blocks of a' of the largest site (qk_fused.h: qkf_turn_add)
   unsigned long long* tail;     // per-launch device clocks (s_memrealtime, 100 MHz): [0] first workgroup start, [1] first workgroup exit, [4] last workgroup exit
+  unsigned long long* err;      // one word per sweep (both launches): set by a DET kernel whose ordered accumulation ran out of patience (qk_get_stats fails the call)
   unsigned long long* prof;  // diagnostic build only: cycle sums per section (see QK_VARIANT=9)
   int debug_flags;           // timing experiments only (QK_DEBUG_FLAGS): bit 0 = skip epilogue stores, bit 1 = skip steady-state fetch/stash, bit 2 = skip MFMAs, bit 3 = skip steady-state barriers (all give WRONG results)
   int prio_mode;             // 0: none; 1: second half of the grid at s_setprio 1; 2: odd blocks at s_setprio 1

@@ -73,6 +73,18 @@ struct QkfTile {  // a 16 x 16 complex tile in the C/D register layout: 16 VGPRs
 __device__ __forceinline__ v2d qkf_ldg(const v2d* __restrict__ base, const unsigned off) {
   return *reinterpret_cast<const v2d*>(reinterpret_cast<const char*>(base) + (size_t)(off * 16u));
 }
+// experiment builds (-DQKF_EXPERIMENT -DQKF_NT_A=1 / -DQKF_NT_B=1): the phase-2 (A) / phase-1 (B) fragment stream with non-temporal loads
+#ifndef QKF_NT_A
+#define QKF_NT_A 0
+#endif
+#ifndef QKF_NT_B
+#define QKF_NT_B 0
+#endif
+__device__ __forceinline__ v2d qkf_ldg_nt(const v2d* __restrict__ base, const unsigned off) {
+  return __builtin_nontemporal_load(reinterpret_cast<const v2d*>(reinterpret_cast<const char*>(base) + (size_t)(off * 16u)));
+}
+__device__ __forceinline__ v2d qkf_ldg_a(const v2d* __restrict__ base, const unsigned off) { return QKF_NT_A ? qkf_ldg_nt(base, off) : qkf_ldg(base, off); }
+__device__ __forceinline__ v2d qkf_ldg_b(const v2d* __restrict__ base, const unsigned off) { return QKF_NT_B ? qkf_ldg_nt(base, off) : qkf_ldg(base, off); }
 __device__ __forceinline__ v2d qkf_ldx(const v2d* __restrict__ base, const unsigned off) { return qkf_ldg(base, off); }
 __device__ __forceinline__ v2d qkf_ldx(const lds_v2d* base, const unsigned off) { return base[off]; }
 
@@ -110,7 +122,7 @@ __device__ __forceinline__ void qkf_p1_tile(QkfTile& t, v2d (&fr)[4], const bool
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       qkf_kstep<false>(p1, p2, p3, fx[i].x, fx[i].y, fr[i].x, fr[i].y);
-      fr[i] = qkf_ldg(cur.base + i * cur.step, cur.off), fx[i] = qkf_ldx(xp + i * xstep, xoff);
+      fr[i] = qkf_ldg_b(cur.base + i * cur.step, cur.off), fx[i] = qkf_ldx(xp + i * xstep, xoff);
       __builtin_amdgcn_sched_barrier(0);
     }
   }
@@ -125,14 +137,59 @@ __device__ __forceinline__ void qkf_p1_tile(QkfTile& t, v2d (&fr)[4], const bool
   t.im = p3 - p1 - p2;
 }
 
+// ORDERED accumulation (the DET forms of the kernels: bit-reproducible sweeps).  The contributions to one 16 x 16 block of X' -- one per
+// (ta, p) -- are added in the order of their index i = pd ta + p instead of in arrival order: the block has a turn counter in LDS, the
+// contribution of index 0 STORES (so X' needs no zeroing pass, and an LDS-resident site with X and X' side by side needs no barrier between
+// its phases), index i waits until the counter reads i, adds and passes the turn on.  Waits always go to a lower index, and a wave takes
+// its units in increasing order, so the chain cannot lock; waves that keep pace wait a few cycles per block (the LDS unit serialises adds
+// to one block anyway).  The counters of a step are zeroed during the step before (two sets, alternating).
+typedef __attribute__((address_space(3))) int lds_int;
+struct QkfTurn {
+  lds_int* at;                 // the turn counters of this contribution's block of rows, one per column block tn
+  int idx;                     // its place in the order
+  lds_int* broken;             // sticky flag of the workgroup: a wait ran out (a bug, never seen) -- every later wait is skipped, the launch ends
+  unsigned long long* gerr;    // ... and is reported through this word (qk_get_stats fails the call)
+};
+__device__ __forceinline__ void qkf_turn_add(__attribute__((address_space(3))) double* const d, const long rs, const v4d& re, const v4d& im, const QkfTurn& t, const int tn) {
+  lds_int* const turn = t.at + tn;
+  if (t.idx > 0) {
+    int spins = 0;
+#ifdef QKF_FIRST_STORE  // experiment: only the FIRST contribution is ordered (it stores: no zeroing, no barrier between the phases); the others add in arrival order
+    while (__builtin_amdgcn_readfirstlane(__hip_atomic_load(turn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) == 0) {
+#else
+    while (__builtin_amdgcn_readfirstlane(__hip_atomic_load(turn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) != t.idx) {
+#endif
+      __builtin_amdgcn_s_sleep(1);
+      if (++spins > (1 << 20) || __builtin_amdgcn_readfirstlane(__hip_atomic_load(t.broken, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) != 0) {  // never a hung GPU
+        __hip_atomic_store(t.broken, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (t.gerr) *t.gerr = 1ull;
+        break;
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      __hip_atomic_fetch_add(d + r * rs, re[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      __hip_atomic_fetch_add(d + r * rs + 1, im[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+  } else {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) *(lds_v2d*)(d + r * rs) = (v2d){re[r], im[r]};
+  }
+#ifdef QKF_FIRST_STORE
+  if (t.idx > 0) return;
+#endif
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this wave's adds have left the LDS queue before the turn moves on
+  __hip_atomic_store(turn, t.idx + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
 // Phase 2, one item: X'[tb rows, tn cols] += T^T conj(A[16 ta + ., p, 16 tn + .]) for every column block tn, added into
 // the LDS image `xo` (row stride a2, this item's 16 rows start at xo) with ds_add_f64.  A operand: stream `cur` (group
 // = column block tn: off advances by 16 per group; step = one k-step = 4 rows of a).  FULL: all four k-steps of this ta
 // block lie below the true bond (every block but the last one of a ragged bond); otherwise kmax of them do.  The last
 // group reloads the registers with the first group of `nxt` (the wave's next item, or its first tile of the next site).
-template <bool FULL>
+template <bool FULL, bool DET = false>
 __device__ __forceinline__ void qkf_p2_item(const QkfTile& t, v2d (&fr)[4], const bool primed, QkfStream cur, const int a2, const int nn, const int kmax, lds_v2d* xo, const int q,
-                                            const int j, const QkfStream nxt) {
+                                            const int j, const QkfStream nxt, const QkfTurn turn = QkfTurn{nullptr, 0, nullptr, nullptr}) {
   if (!primed) qkf_load4(fr, cur);
   __attribute__((address_space(3))) double* d = (__attribute__((address_space(3))) double*)(xo + q * a2 + j);
 #pragma unroll 1
@@ -146,15 +203,18 @@ __device__ __forceinline__ void qkf_p2_item(const QkfTile& t, v2d (&fr)[4], cons
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       if (FULL || i < kmax) qkf_kstep<true>(p1, p2, p3, t.re[i], t.im[i], fr[i].x, fr[i].y);
-      fr[i] = qkf_ldg(rb + i * rs, cur.off);
+      fr[i] = qkf_ldg_a(rb + i * rs, cur.off);
       __builtin_amdgcn_sched_barrier(0);
     }
     QKF_PRIO_HI();
     const v4d re = p1 + p2, im = p3 - p1 + p2;
+    if constexpr (DET) qkf_turn_add(d, (long)8 * a2, re, im, turn, tn);
+    else {
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      __hip_atomic_fetch_add(d + (long)r * 8 * a2, re[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-      __hip_atomic_fetch_add(d + (long)r * 8 * a2 + 1, im[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      for (int r = 0; r < 4; ++r) {
+        __hip_atomic_fetch_add(d + (long)r * 8 * a2, re[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __hip_atomic_fetch_add(d + (long)r * 8 * a2 + 1, im[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      }
     }
     d += 2 * TILE;
   }
@@ -230,7 +290,7 @@ __device__ __forceinline__ void qkf_edge_prefix(const SweepArgs& g, const int xi
 }
 
 // The overlap at the right edge: z = sum_{b,a} X[b][a] R[b][a], R = Ry^T conj(Rx); X row-major with stride a at `xin`.  Every
-// wavefront adds its tiles' share to the two doubles at `zacc` (LDS, zeroed by the caller behind a barrier).
+// wavefront leaves its tiles' share in its own two doubles of `zacc` (LDS, [NW][2]); the caller adds them up in wavefront order behind a barrier.
 template <int NW, typename XIn>
 __device__ __forceinline__ void qkf_edge_suffix(const SweepArgs& g, const int xi, const int yj, const int a, const int b, XIn xin, __attribute__((address_space(3))) double* zacc, const int wave,
                                                 const int q, const int j) {
@@ -250,10 +310,7 @@ __device__ __forceinline__ void qkf_edge_suffix(const SweepArgs& g, const int xi
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) zr += __shfl_xor(zr, o), zi += __shfl_xor(zi, o);
-  if ((q | j) == 0 && wave < mt * nt) {
-    __hip_atomic_fetch_add(zacc, zr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    __hip_atomic_fetch_add(zacc + 1, zi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-  }
+  if ((q | j) == 0) zacc[2 * wave] = zr, zacc[2 * wave + 1] = zi;  // one slot per wavefront: the caller adds them up in wavefront order (reproducible)
 }
 
 // What a site needs: bonds, tile counts, where its X / X' live and how its items are cut into strips.
@@ -328,7 +385,32 @@ __device__ __forceinline__ void qkf_step_table(const SweepArgs& g, const int xi,
   }
 }
 
-template <int NW, int S, int XCAP, int WPS>  // waves per workgroup; T slots per wave (a round holds NW * S items); elements of the LDS X buffer; waves per SIMD (register budget)
+// experiment builds only (-DQKF_PROF): cycle sums per section of a wave's life, added up over all waves into SweepArgs.prof[0..7]
+// (lab/tools/fused_sections.py; printed by qk_get_stats of such a build)
+#ifdef QKF_PROF
+#define QKF_PROF_DECL() \
+  unsigned long long pf[8] = {0, 0, 0, 0, 0, 0, 0, 0}, pt = __builtin_amdgcn_s_memtime(); \
+  const unsigned long long pt0 = pt
+#define QKF_STAMP(i)                                              \
+  do {                                                            \
+    const unsigned long long now_ = __builtin_amdgcn_s_memtime(); \
+    pf[i] += now_ - pt;                                           \
+    pt = now_;                                                    \
+  } while (0)
+#define QKF_PROF_FLUSH()                                             \
+  do {                                                               \
+    if (lane == 0) {                                                 \
+      pf[7] = __builtin_amdgcn_s_memtime() - pt0;                    \
+      for (int i_ = 0; i_ < 8; ++i_) atomicAdd(g.prof + i_, pf[i_]); \
+    }                                                                \
+  } while (0)
+#else
+#define QKF_PROF_DECL()
+#define QKF_STAMP(i)
+#define QKF_PROF_FLUSH()
+#endif
+
+template <int NW, int S, int XCAP, int WPS, bool DET = false>  // waves per workgroup; T slots per wave (a round holds NW * S items); elements of the LDS X buffer; waves per SIMD (register budget); ordered accumulation (bit-reproducible)
 __global__ __launch_bounds__(64 * NW, WPS) void qk_sweep_fused_kernel(const SweepArgs g) {
   constexpr int NT = 64 * NW;
   extern __shared__ __attribute__((aligned(16))) double lds_raw[];
@@ -342,9 +424,11 @@ __global__ __launch_bounds__(64 * NW, WPS) void qk_sweep_fused_kernel(const Swee
   const int j = lane & 15, q = lane >> 4;
   const int ns = g.n_sites;
   // the step table of the current pair (qkf_step_table): 12 ints per step, and the addresses of the step's two tensors in a second table
-  __attribute__((address_space(3))) double* const zacc = (__attribute__((address_space(3))) double*)(slot + 2);  // the overlap's two doubles (edge blocks)
-  lds_v4i* const rec = (lds_v4i*)(slot + 4);
-  long long* const m_off = reinterpret_cast<long long*>(slot + 4) + 6 * (long long)ns;  // [ns][2]: A_k, B_k
+  __attribute__((address_space(3))) double* const zacc = (__attribute__((address_space(3))) double*)(slot + 2);  // the overlap's partial sums (edge blocks): [16 wavefronts][2]
+  lds_v4i* const rec = (lds_v4i*)(slot + 2 + 32);
+  long long* const m_off = reinterpret_cast<long long*>(slot + 2 + 32) + 6 * (long long)ns;  // [ns][2]: A_k, B_k
+  lds_int* const tbroken = (lds_int*)(m_off + 2 * (long long)ns);  // DET: the workgroup's sticky 'a wait ran out' flag, then
+  lds_int* const turn0 = tbroken + 2;                              // two sets of g.turn_ints turn counters (qkf_turn_add)
   auto rfl = [&](const int v) __attribute__((always_inline)) { return __builtin_amdgcn_readfirstlane(v); };
   auto ldl = [&](const long long* p_) __attribute__((always_inline)) {
     const long long v = *p_;
@@ -373,18 +457,7 @@ __global__ __launch_bounds__(64 * NW, WPS) void qk_sweep_fused_kernel(const Swee
     const int pp = it & (s.pd - 1), u = it >> s.ps, tbl = (u * s.inv) >> 20, ta = u - tbl * s.mt;
     return QkfStream{s.Ak + pp * s.a2, (unsigned)(((ta * TILE + q) * s.pd) * s.a2 + j), 4 * s.pd * s.a2};
   };
-#ifdef QKF_PROF  // experiment builds only: cycle sums per section of a wave's life (tools/fused_sections.py)
-  unsigned long long pf[8] = {0, 0, 0, 0, 0, 0, 0, 0}, pt = __builtin_amdgcn_s_memtime();
-  const unsigned long long pt0 = pt;
-#define QKF_STAMP(i)                                              \
-  do {                                                            \
-    const unsigned long long now_ = __builtin_amdgcn_s_memtime(); \
-    pf[i] += now_ - pt;                                           \
-    pt = now_;                                                    \
-  } while (0)
-#else
-#define QKF_STAMP(i)
-#endif
+  QKF_PROF_DECL();
   const int xcc = qk_xcc_id();
   if (tid == 0) qk_tail_start(g);
   for (;;) {
@@ -402,7 +475,9 @@ __global__ __launch_bounds__(64 * NW, WPS) void qk_sweep_fused_kernel(const Swee
     const bool edges = ek > 0;
     if (!edges)
       for (int e = tid; e < TILE * TILE; e += NT) XL[e] = (v2d){e == 0 ? 1.0 : 0.0, 0.0};  // X_0 = 1 in a 16 x 16 block
-    if (tid == 0) zacc[0] = 0.0, zacc[1] = 0.0;
+    if constexpr (DET)
+      for (int e = tid; e < 2 * g.turn_ints + 2; e += NT) tbroken[e] = 0;
+    int tsel = 0;  // DET: the set of turn counters in use (the other one is zeroed meanwhile for the next strip or step)
     __syncthreads();
     bool xg = false;  // where X lives: LDS (at element xb, row stride a) or the global buffer G0 + cur * x_plane
     int cur = 0, xb = 0;
@@ -442,12 +517,15 @@ __global__ __launch_bounds__(64 * NW, WPS) void qk_sweep_fused_kernel(const Swee
       const int n_out = sc.b2 * a2;
       const bool pingpong = small && a * b + n_out <= XCAP;
       const int ob = !small ? 0 : pingpong ? (xb == 0 ? XCAP - n_out : 0) : 0;  // where X' (or the strip of X') is built
-      if (pingpong)
+      if (pingpong && !DET)
         for (int e = tid; e < n_out; e += NT) XL[ob + e] = (v2d){0.0, 0.0};
       QKF_STAMP(1);  // X moved between LDS and the global buffer
       for (int s0 = 0; s0 < nt; s0 += W) {
         const int w = min(W, nt - s0), items = sc.pd * mt * w;
-        if (!small) {  // zero this strip's X' rows (the LDS-resident path zeroes after phase 1: X is still being read)
+        lds_int* const tcur = turn0 + tsel * g.turn_ints;
+        if constexpr (DET) {  // (ordered accumulation: the first contribution to a block stores, nothing is zeroed but the next set of counters)
+          for (int e = tid; e < g.turn_ints; e += NT) turn0[(tsel ^ 1) * g.turn_ints + e] = 0;
+        } else if (!small) {  // zero this strip's X' rows (the LDS-resident path zeroes after phase 1: X is still being read)
           for (int e = tid; e < w * TILE * a2; e += NT) XL[e] = (v2d){0.0, 0.0};
           qk_lds_barrier();
         }
@@ -474,9 +552,9 @@ __global__ __launch_bounds__(64 * NW, WPS) void qk_sweep_fused_kernel(const Swee
           if (xg) phase1((const v2d*)Gc);
           else phase1((const lds_v2d*)(XL + xb));
           QKF_STAMP(2);  // phase 1
-          if (small && r0 == 0) {
+          if (small && r0 == 0 && !(DET && pingpong)) {
             qk_lds_barrier();  // ping-pong: X' is zero everywhere; in place (one round): every wave has read X, it becomes X'
-            if (!pingpong) {
+            if (!pingpong && !DET) {
               for (int e = tid; e < n_out; e += NT) XL[e] = (v2d){0.0, 0.0};
               qk_lds_barrier();
             }
@@ -495,13 +573,16 @@ __global__ __launch_bounds__(64 * NW, WPS) void qk_sweep_fused_kernel(const Swee
             // after the wave's last item of the site: its first tile of the next site (strip 0, round 0), if it has one
             const bool chain = !more && last_round && k < k_hi && wave < sn.pd * sn.mt * min(sn.W, sn.nt);
             const QkfStream nxt = more ? a_stream(sc, it + NW) : chain ? b_stream(sn, 0, wave) : a_stream(sc, it);
-            if (kmax == 4) qkf_p2_item<true>(T[S - 1], fr, primed, a_stream(sc, it), a2, sc.nn, 4, XL + ob + tbl * TILE * a2, q, j, nxt);
-            else qkf_p2_item<false>(T[S - 1], fr, primed, a_stream(sc, it), a2, sc.nn, kmax, XL + ob + tbl * TILE * a2, q, j, nxt);
+            const int tix = sc.pd * ta + (it & (sc.pd - 1));  // this contribution's place in the order of its block of rows
+            const QkfTurn turn{tcur + tbl * sc.nn, tix, tbroken, g.err};
+            if (kmax == 4) qkf_p2_item<true, DET>(T[S - 1], fr, primed, a_stream(sc, it), a2, sc.nn, 4, XL + ob + tbl * TILE * a2, q, j, nxt, turn);
+            else qkf_p2_item<false, DET>(T[S - 1], fr, primed, a_stream(sc, it), a2, sc.nn, kmax, XL + ob + tbl * TILE * a2, q, j, nxt, turn);
             primed = more || chain;
           }
           QKF_STAMP(4);  // phase 2
         }
         qk_lds_barrier();  // the strip of X' is complete
+        tsel ^= 1;
         QKF_STAMP(5);      // wait for the other waves' phase 2
         if (!small && nt > W) {  // several strips: this one goes to the other global buffer
           for (int e = tid; e < w * TILE * a2; e += NT) Gn[(long long)s0 * TILE * a2 + e] = XL[e];
@@ -524,7 +605,10 @@ __global__ __launch_bounds__(64 * NW, WPS) void qk_sweep_fused_kernel(const Swee
       __syncthreads();
     }
     if (tid == 0) {
-      const v2d zz = edges ? (v2d){zacc[0], zacc[1]} : xg ? G0[(long long)cur * g.x_plane] : (v2d)XL[xb];
+      v2d zz = {0.0, 0.0};
+      if (edges)
+        for (int w_ = 0; w_ < NW; ++w_) zz.x += zacc[2 * w_], zz.y += zacc[2 * w_ + 1];
+      else zz = xg ? G0[(long long)cur * g.x_plane] : (v2d)XL[xb];
       g.values[p] = zz.x * zz.x + zz.y * zz.y;
       if (g.z) {
         g.z[2 * p] = zz.x;
@@ -534,12 +618,7 @@ __global__ __launch_bounds__(64 * NW, WPS) void qk_sweep_fused_kernel(const Swee
     __syncthreads();
   }
   if (tid == 0) qk_tail_exit(g);
-#ifdef QKF_PROF
-  if (lane == 0) {
-    pf[7] = __builtin_amdgcn_s_memtime() - pt0;
-    for (int i = 0; i < 8; ++i) atomicAdd(g.prof + i, pf[i]);
-  }
-#endif
+  QKF_PROF_FLUSH();
 }
 
 // ----------------------------------------------------------------------------------------
@@ -569,8 +648,8 @@ __device__ __forceinline__ void qkf_p1_dual(QkfTile& t0, QkfTile& t1, v2d (&fr)[
     for (int i = 0; i < 4; ++i) {
       qkf_kstep<false>(p1, p2, p3, fx[i].x, fx[i].y, fr[i].x, fr[i].y);
       if (HAS1) qkf_kstep<false>(r1, r2, r3, fx[i].x, fx[i].y, fs[i].x, fs[i].y);
-      fr[i] = qkf_ldg(cur.base + i * cur.step, cur.off);
-      if (HAS1) fs[i] = qkf_ldg(cur.base + i * cur.step, cur.off + TILE);
+      fr[i] = qkf_ldg_b(cur.base + i * cur.step, cur.off);
+      if (HAS1) fs[i] = qkf_ldg_b(cur.base + i * cur.step, cur.off + TILE);
       fx[i] = qkf_ldx(xp + i * xstep, xoff);
       __builtin_amdgcn_sched_barrier(0);
     }
@@ -591,9 +670,9 @@ __device__ __forceinline__ void qkf_p1_dual(QkfTile& t0, QkfTile& t1, v2d (&fr)[
 
 // Phase 2 of a pair of tiles: X'[tb0 rows | tb0 + 1 rows, tn cols] += T0^T | T1^T conj(A[16 ta + ., p, 16 tn + .]).  `nxt` is the
 // wave's next phase-1 stream (NXT_P1: both column blocks are loaded, the second one at + n1 elements) or a dummy.
-template <bool FULL, bool HAS1>
+template <bool FULL, bool HAS1, bool DET = false>
 __device__ __forceinline__ void qkf_p2_dual(const QkfTile& t0, const QkfTile& t1, v2d (&fr)[4], v2d (&fs)[4], QkfStream cur, const int a2, const int nn, const int kmax, lds_v2d* xo, const int q,
-                                            const int j, const QkfStream nxt, const bool nxt_p1, const unsigned n1) {
+                                            const int j, const QkfStream nxt, const bool nxt_p1, const unsigned n1, const QkfTurn turn = QkfTurn{nullptr, 0, nullptr, nullptr}) {
   __attribute__((address_space(3))) double* d = (__attribute__((address_space(3))) double*)(xo + q * a2 + j);
 #pragma unroll 1
   for (int tn = 0; tn < nn; ++tn) {
@@ -609,32 +688,38 @@ __device__ __forceinline__ void qkf_p2_dual(const QkfTile& t0, const QkfTile& t1
         qkf_kstep<true>(p1, p2, p3, t0.re[i], t0.im[i], fr[i].x, fr[i].y);
         if (HAS1) qkf_kstep<true>(r1, r2, r3, t1.re[i], t1.im[i], fr[i].x, fr[i].y);
       }
-      fr[i] = qkf_ldg(rb + i * rs, cur.off);
+      fr[i] = qkf_ldg_a(rb + i * rs, cur.off);
       __builtin_amdgcn_sched_barrier(0);
     }
     QKF_PRIO_HI();
     {
       const v4d re = p1 + p2, im = p3 - p1 + p2;
+      if constexpr (DET) qkf_turn_add(d, (long)8 * a2, re, im, turn, tn);
+      else {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        __hip_atomic_fetch_add(d + (long)r * 8 * a2, re[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        __hip_atomic_fetch_add(d + (long)r * 8 * a2 + 1, im[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        for (int r = 0; r < 4; ++r) {
+          __hip_atomic_fetch_add(d + (long)r * 8 * a2, re[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          __hip_atomic_fetch_add(d + (long)r * 8 * a2 + 1, im[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
       }
     }
     if (HAS1) {
       const v4d re = r1 + r2, im = r3 - r1 + r2;
       __attribute__((address_space(3))) double* const d1 = d + (long)2 * TILE * a2;  // 16 rows further down
+      if constexpr (DET) qkf_turn_add(d1, (long)8 * a2, re, im, QkfTurn{turn.at + nn, turn.idx, turn.broken, turn.gerr}, tn);  // (the counters of the next block of rows follow)
+      else {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        __hip_atomic_fetch_add(d1 + (long)r * 8 * a2, re[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        __hip_atomic_fetch_add(d1 + (long)r * 8 * a2 + 1, im[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        for (int r = 0; r < 4; ++r) {
+          __hip_atomic_fetch_add(d1 + (long)r * 8 * a2, re[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          __hip_atomic_fetch_add(d1 + (long)r * 8 * a2 + 1, im[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
       }
     }
     d += 2 * TILE;
   }
 }
 
-template <int NW, int XCAP, int WPS>  // waves per workgroup (a round holds NW pairs of tiles); elements of the LDS X buffer; waves per SIMD (register budget)
+template <int NW, int XCAP, int WPS, bool DET = false>  // waves per workgroup (a round holds NW pairs of tiles); elements of the LDS X buffer; waves per SIMD (register budget); ordered accumulation (bit-reproducible)
 __global__ __launch_bounds__(64 * NW, WPS) void qk_sweep_fused_dual_kernel(const SweepArgs g) {
   constexpr int NT = 64 * NW;
   extern __shared__ __attribute__((aligned(16))) double lds_raw[];
@@ -647,9 +732,11 @@ __global__ __launch_bounds__(64 * NW, WPS) void qk_sweep_fused_dual_kernel(const
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int j = lane & 15, q = lane >> 4;
   const int ns = g.n_sites;
-  __attribute__((address_space(3))) double* const zacc = (__attribute__((address_space(3))) double*)(slot + 2);
-  lds_v4i* const rec = (lds_v4i*)(slot + 4);  // per-site records as in qk_sweep_fused_kernel
-  long long* const m_off = reinterpret_cast<long long*>(slot + 4) + 6 * (long long)ns;
+  __attribute__((address_space(3))) double* const zacc = (__attribute__((address_space(3))) double*)(slot + 2);  // [16 wavefronts][2]
+  lds_v4i* const rec = (lds_v4i*)(slot + 2 + 32);  // per-site records as in qk_sweep_fused_kernel
+  long long* const m_off = reinterpret_cast<long long*>(slot + 2 + 32) + 6 * (long long)ns;
+  lds_int* const tbroken = (lds_int*)(m_off + 2 * (long long)ns);  // DET: the workgroup's sticky 'a wait ran out' flag, then
+  lds_int* const turn0 = tbroken + 2;                              // two sets of g.turn_ints turn counters (qkf_turn_add)
   auto rfl = [&](const int v) __attribute__((always_inline)) { return __builtin_amdgcn_readfirstlane(v); };
   auto ldl = [&](const long long* p_) __attribute__((always_inline)) {
     const long long v = *p_;
@@ -698,6 +785,7 @@ __global__ __launch_bounds__(64 * NW, WPS) void qk_sweep_fused_dual_kernel(const
     const int pp = v & (s.pd - 1), u = v >> s.ps, tp = (u * s.inv) >> 20, ta = u - tp * s.mt;
     return QkfStream{s.Ak + pp * s.a2, (unsigned)(((ta * TILE + q) * s.pd) * s.a2 + j), 4 * s.pd * s.a2};
   };
+  QKF_PROF_DECL();
   const int xcc = qk_xcc_id();
   if (tid == 0) qk_tail_start(g);
   for (;;) {
@@ -714,7 +802,9 @@ __global__ __launch_bounds__(64 * NW, WPS) void qk_sweep_fused_dual_kernel(const
     const bool edges = ek > 0;
     if (!edges)
       for (int e = tid; e < TILE * TILE; e += NT) XL[e] = (v2d){e == 0 ? 1.0 : 0.0, 0.0};
-    if (tid == 0) zacc[0] = 0.0, zacc[1] = 0.0;
+    if constexpr (DET)
+      for (int e = tid; e < 2 * g.turn_ints + 2; e += NT) tbroken[e] = 0;
+    int tsel = 0;  // DET: the set of turn counters in use (the other one is zeroed meanwhile for the next strip or step)
     __syncthreads();
     bool xg = false;
     int cur = 0, xb = 0;
@@ -725,6 +815,7 @@ __global__ __launch_bounds__(64 * NW, WPS) void qk_sweep_fused_dual_kernel(const
       else qkf_edge_prefix<NW>(g, xi, yj, a_e, b_e, G0, wave, q, j), xg = true;
       __syncthreads();
     }
+    QKF_STAMP(0);  // pair set-up (queue, step table, left edge)
     QkfTile T0, T1;
     v2d fr[4], fs[4];     // the fragment registers of the wave's global streams (fs: the second column block of phase 1)
     bool primed = false;  // fr / fs hold the first group of the wave's next pair of tiles
@@ -749,11 +840,15 @@ __global__ __launch_bounds__(64 * NW, WPS) void qk_sweep_fused_dual_kernel(const
       const int n_out = sc.b2 * a2;
       const bool pingpong = small && a * b + n_out <= XCAP;
       const int ob = !small ? 0 : pingpong ? (xb == 0 ? XCAP - n_out : 0) : 0;
-      if (pingpong)
+      if (pingpong && !DET)
         for (int e = tid; e < n_out; e += NT) XL[ob + e] = (v2d){0.0, 0.0};
+      QKF_STAMP(1);  // step set-up: record decode, X moved between LDS and the global buffer, X' zeroed (ping-pong)
       for (int s0 = 0; s0 < nt; s0 += W) {
         const int w = min(W, nt - s0), units = sc.pd * mt * ((w + 1) >> 1);
-        if (!small) {
+        lds_int* const tcur = turn0 + tsel * g.turn_ints;
+        if constexpr (DET) {  // (ordered accumulation: the first contribution to a block stores, nothing is zeroed but the next set of counters)
+          for (int e = tid; e < g.turn_ints; e += NT) turn0[(tsel ^ 1) * g.turn_ints + e] = 0;
+        } else if (!small) {
           for (int e = tid; e < w * TILE * a2; e += NT) XL[e] = (v2d){0.0, 0.0};
           qk_lds_barrier();
         }
@@ -773,13 +868,15 @@ __global__ __launch_bounds__(64 * NW, WPS) void qk_sweep_fused_dual_kernel(const
               else qkf_p1_dual<false>(T0, T1, fr, fs, primed, bs, (const lds_v2d*)(XL + xb), xoff, 4 * a, sc.nks, as);
             }
           }
-          if (small && r0 == 0) {
+          QKF_STAMP(2);  // phase 1
+          if (small && r0 == 0 && !(DET && pingpong)) {
             qk_lds_barrier();  // ping-pong: X' is zero everywhere; in place (one round): every wave has read X, it becomes X'
-            if (!pingpong) {
+            if (!pingpong && !DET) {
               for (int e = tid; e < n_out; e += NT) XL[e] = (v2d){0.0, 0.0};
               qk_lds_barrier();
             }
           }
+          QKF_STAMP(3);  // wait for the other waves' phase 1 (LDS-resident steps), zero X'
           if (mine) {
             const int kmax = min(4, (sc.at - ta * TILE + 3) >> 2);
             // what the wave does next: its unit of the next round of this strip, of the first round of the next strip, or of
@@ -800,17 +897,22 @@ __global__ __launch_bounds__(64 * NW, WPS) void qk_sweep_fused_dual_kernel(const
             }
             const unsigned nd1 = 0;
             lds_v2d* const xo = XL + ob + (2 * tp + un.half) * TILE * a2;
+            // the turn counters of this block of rows and this contribution's place in their order
+            const QkfTurn tp_turn{tcur + (2 * tp + un.half) * sc.nn, sc.pd * ta + (v & (sc.pd - 1)), tbroken, g.err};
             if (has1) {
-              if (kmax == 4) qkf_p2_dual<true, true>(T0, T1, fr, fs, a_stream(sc, v), a2, sc.nn, 4, xo, q, j, nxt, np1, nd1);
-              else qkf_p2_dual<false, true>(T0, T1, fr, fs, a_stream(sc, v), a2, sc.nn, kmax, xo, q, j, nxt, np1, nd1);
+              if (kmax == 4) qkf_p2_dual<true, true, DET>(T0, T1, fr, fs, a_stream(sc, v), a2, sc.nn, 4, xo, q, j, nxt, np1, nd1, tp_turn);
+              else qkf_p2_dual<false, true, DET>(T0, T1, fr, fs, a_stream(sc, v), a2, sc.nn, kmax, xo, q, j, nxt, np1, nd1, tp_turn);
             } else {
-              if (kmax == 4) qkf_p2_dual<true, false>(T0, T1, fr, fs, a_stream(sc, v), a2, sc.nn, 4, xo, q, j, nxt, np1, nd1);
-              else qkf_p2_dual<false, false>(T0, T1, fr, fs, a_stream(sc, v), a2, sc.nn, kmax, xo, q, j, nxt, np1, nd1);
+              if (kmax == 4) qkf_p2_dual<true, false, DET>(T0, T1, fr, fs, a_stream(sc, v), a2, sc.nn, 4, xo, q, j, nxt, np1, nd1, tp_turn);
+              else qkf_p2_dual<false, false, DET>(T0, T1, fr, fs, a_stream(sc, v), a2, sc.nn, kmax, xo, q, j, nxt, np1, nd1, tp_turn);
             }
             primed = np1;
           }
+          QKF_STAMP(4);  // phase 2
         }
         qk_lds_barrier();  // the strip of X' is complete
+        tsel ^= 1;
+        QKF_STAMP(5);  // wait for the other waves' phase 2
         if (!small && nt > W) {
           for (int e = tid; e < w * TILE * a2; e += NT) Gn[(long long)s0 * TILE * a2 + e] = XL[e];
           __syncthreads();
@@ -831,7 +933,10 @@ __global__ __launch_bounds__(64 * NW, WPS) void qk_sweep_fused_dual_kernel(const
       __syncthreads();
     }
     if (tid == 0) {
-      const v2d zz = edges ? (v2d){zacc[0], zacc[1]} : xg ? G0[(long long)cur * g.x_plane] : (v2d)XL[xb];
+      v2d zz = {0.0, 0.0};
+      if (edges)
+        for (int w_ = 0; w_ < NW; ++w_) zz.x += zacc[2 * w_], zz.y += zacc[2 * w_ + 1];
+      else zz = xg ? G0[(long long)cur * g.x_plane] : (v2d)XL[xb];
       g.values[p] = zz.x * zz.x + zz.y * zz.y;
       if (g.z) {
         g.z[2 * p] = zz.x;
@@ -839,8 +944,10 @@ __global__ __launch_bounds__(64 * NW, WPS) void qk_sweep_fused_dual_kernel(const
       }
     }
     __syncthreads();
+    QKF_STAMP(6);  // right edge, result
   }
   if (tid == 0) qk_tail_exit(g);
+  QKF_PROF_FLUSH();
 }
 
 // split planes (re | im) of a set image -> interleaved complex (complex128 for double, complex64 for float), same offsets;

@@ -268,16 +268,22 @@ static void tiled_global(TiledGlobal& G, const int n_sites, const int nx, const 
   };
   const std::vector<int> ox = order_of(nx, xt), oy = sym ? ox : order_of(ny, yt);
   // the tiles in (bj, bi) order with their item ranges (counts are known before any work is priced)
-  const int nbx = (nx + T - 1) / T, nby = (ny + T - 1) / T;
+  // (tiles are Tx x-positions by Ty y-positions: square by default; QK_PLAN_TILE_X / QK_PLAN_TILE_Y cut them oblong, e.g. 32 x 2 --
+  //  32 pairs that share each of two y states, whose tensors are the operand every wave of a workgroup re-reads in phase 1)
+  int Tx = T, Ty = T;
+  if (const char* e = std::getenv("QK_PLAN_TILE_X")) Tx = std::max(1, std::min(128, std::atoi(e)));
+  if (const char* e = std::getenv("QK_PLAN_TILE_Y")) Ty = std::max(1, std::min(128, std::atoi(e)));
+  // the order of contraction of a symmetric plan's pairs: per pair (default), or one choice per tile (QK_PLAN_ORIENT_TILE=1: the pairs of
+  // a tile then really share their y states)
+  const bool orient_tile = orient && std::getenv("QK_PLAN_ORIENT_TILE") && std::atoi(std::getenv("QK_PLAN_ORIENT_TILE")) != 0;
+  const int nbx = (nx + Tx - 1) / Tx, nby = (ny + Ty - 1) / Ty;
   std::vector<int32_t> tile_b;  // (bi, bj) of each tile
   int64_t n_items = 0;
   for (int bj = 0; bj < nby; ++bj)
     for (int bi = 0; bi < nbx; ++bi) {
-      if (sym && bi > bj) continue;
-      const int u0 = bi * T, u1 = std::min(nx, (bi + 1) * T), v0 = bj * T, v1 = std::min(ny, (bj + 1) * T);
+      const int u0 = bi * Tx, u1 = std::min(nx, (bi + 1) * Tx), v0 = bj * Ty, v1 = std::min(ny, (bj + 1) * Ty);
       int64_t cnt = 0;
-      if (sym && bi == bj) cnt = (int64_t)(u1 - u0) * (u1 - u0 + 1) / 2;  // u <= v
-      else cnt = (int64_t)(u1 - u0) * (v1 - v0);
+      for (int v = v0; v < v1; ++v) cnt += sym ? std::max(0, std::min(u1, v + 1) - u0) : (u1 - u0);  // symmetric: positions u <= v
       if (cnt == 0) continue;
       tiles.push_back(Tile{n_items, cnt, 0.0});
       tile_b.push_back(bi), tile_b.push_back(bj);
@@ -289,20 +295,31 @@ static void tiled_global(TiledGlobal& G, const int n_sites, const int nx, const 
   par_ranges(threads, (int64_t)tiles.size(), [&](const int64_t t_lo, const int64_t t_hi) {
     for (int64_t t = t_lo; t < t_hi; ++t) {
       const int bi = tile_b[2 * (size_t)t], bj = tile_b[2 * (size_t)t + 1];
-      int64_t q = tiles[(size_t)t].start;
-      double cost = 0;
-      for (int v = bj * T; v < std::min(ny, (bj + 1) * T); ++v)
-        for (int u = bi * T; u < std::min(nx, (bi + 1) * T); ++u) {
+      const int64_t q0 = tiles[(size_t)t].start;
+      int64_t q = q0;
+      double cost = 0, cost_sw = 0, c_keep = 0, c_swap = 0;
+      for (int v = bj * Ty; v < std::min(ny, (bj + 1) * Ty); ++v)
+        for (int u = bi * Tx; u < std::min(nx, (bi + 1) * Tx); ++u) {
           if (sym && u > v) continue;  // positions in the weight order: every unordered pair once
           int xi = ox[(size_t)u], yj = oy[(size_t)v];
           if (sym && !orient && xi > yj) std::swap(xi, yj);  // the plain symmetric list names a pair as i <= j
           const size_t ex = (size_t)xi * n_sites, ey = (size_t)yj * n_sites;
           const Pass1 r = pair_pass1(n_sites, &xt.T0[ex], &xt.T1[ex], &xt.TK[ex], &xt.P0[ex], &xt.P1[ex], &xt.P01[ex], &yt.T0[ey], &yt.T1[ey], &yt.TK[ey], &yt.P0[ey], &yt.P1[ey], &yt.P01[ey]);
           double fp = r.fp_xy;
-          if (orient && xi != yj && r.c_yx < r.c_xy) std::swap(xi, yj), fp = r.fp_yx;
+          if (orient_tile) c_keep += r.c_xy, c_swap += r.c_yx, cost_sw += r.fp_yx;
+          else if (orient && xi != yj && r.c_yx < r.c_xy) std::swap(xi, yj), fp = r.fp_yx;
           items[(size_t)q++] = Item{xi, yj, fp};
           cost += fp;
         }
+      if (orient_tile && c_swap < c_keep) {  // the whole tile in the other order
+        for (int64_t e = q0; e < q; ++e) {
+          Item& it = items[(size_t)e];
+          const size_t ex = (size_t)it.j * n_sites, ey = (size_t)it.i * n_sites;
+          const Pass1 r = pair_pass1(n_sites, &xt.T0[ex], &xt.T1[ex], &xt.TK[ex], &xt.P0[ex], &xt.P1[ex], &xt.P01[ex], &yt.T0[ey], &yt.T1[ey], &yt.TK[ey], &yt.P0[ey], &yt.P1[ey], &yt.P01[ey]);
+          std::swap(it.i, it.j), it.fp = r.fp_xy;
+        }
+        cost = cost_sw;
+      }
       tiles[(size_t)t].cost = cost;
     }
   });

@@ -167,6 +167,26 @@ extern "C" int qk_pack_state(int32_t n_sites, const int32_t* bond_dims, const do
 #define QKF_DUAL_WPS 3
 #endif
 #define QKF_KERNEL_DUAL qk_sweep_fused_dual_kernel<QKF_DUAL_NW, QKF_XCAP_ONE, QKF_DUAL_WPS>
+// the DET forms (QK_DETERMINISTIC=1): ordered accumulation into X' (qk_fused.h: qkf_turn_add) -- bit-reproducible Grams
+#define QKF_KERNEL_ONE_DET qk_sweep_fused_kernel<QKF_ONE_NW, QKF_ONE_S, QKF_XCAP_ONE, QKF_ONE_WPS, true>
+#define QKF_KERNEL_TWO_DET qk_sweep_fused_kernel<QKF_TWO_NW, QKF_TWO_S, QKF_XCAP_TWO, QKF_TWO_WPS, true>
+#define QKF_KERNEL_DUAL_DET qk_sweep_fused_dual_kernel<QKF_DUAL_NW, QKF_XCAP_ONE, QKF_DUAL_WPS, true>
+// launch one of the three shapes in its plain or DET form
+#define QKF_LAUNCH_ONE(det, grid_, lds_, args_)                                                                      \
+  do {                                                                                                               \
+    if (det) QKF_KERNEL_ONE_DET<<<dim3((unsigned)(grid_)), dim3(64 * QKF_ONE_NW), (lds_), c->stream>>>(args_);       \
+    else QKF_KERNEL_ONE<<<dim3((unsigned)(grid_)), dim3(64 * QKF_ONE_NW), (lds_), c->stream>>>(args_);               \
+  } while (0)
+#define QKF_LAUNCH_TWO(det, grid_, lds_, args_)                                                                      \
+  do {                                                                                                               \
+    if (det) QKF_KERNEL_TWO_DET<<<dim3((unsigned)(grid_)), dim3(64 * QKF_TWO_NW), (lds_), c->stream>>>(args_);       \
+    else QKF_KERNEL_TWO<<<dim3((unsigned)(grid_)), dim3(64 * QKF_TWO_NW), (lds_), c->stream>>>(args_);               \
+  } while (0)
+#define QKF_LAUNCH_DUAL(det, grid_, lds_, args_)                                                                     \
+  do {                                                                                                               \
+    if (det) QKF_KERNEL_DUAL_DET<<<dim3((unsigned)(grid_)), dim3(64 * QKF_DUAL_NW), (lds_), c->stream>>>(args_);     \
+    else QKF_KERNEL_DUAL<<<dim3((unsigned)(grid_)), dim3(64 * QKF_DUAL_NW), (lds_), c->stream>>>(args_);             \
+  } while (0)
 
 extern "C" int qk_plan_destroy(qk_plan* plan) {
   if (!plan) return QK_OK;
@@ -393,6 +413,9 @@ static int ctx_init(qk_ctx* c, int device_id, int num_cus) {
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(QKF_KERNEL_ONE), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(QKF_KERNEL_TWO), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(QKF_KERNEL_DUAL), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(QKF_KERNEL_ONE_DET), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(QKF_KERNEL_TWO_DET), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(QKF_KERNEL_DUAL_DET), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
 #ifdef QK_LAB  // libqklab.so only: the experimental kernels of qk_lab.hip, selectable with QK_VARIANT
   {
     const int rc = qk_lab_init(c);
@@ -405,12 +428,12 @@ static int ctx_init(qk_ctx* c, int device_id, int num_cus) {
   if (const char* v = std::getenv("QK_WAVE2")) c->wave2_path = std::atoi(v) != 0, c->wave2_ring = std::atoi(v) != 2;
   if (const char* v = std::getenv("QK_FUSED")) c->fused_path = std::atoi(v);
   if (const char* v = std::getenv("QK_MERGE")) c->merge_sites = std::atoi(v) != 0;
-  // QK_DETERMINISTIC=1: bit-reproducible Grams.  The site-fused sweep sums the tiles of a column with LDS atomics in arrival
-  // order (two launches on the same inputs differ in the last bits, <= 9e-16); the ring sweep, the small-bond sweep and the
-  // one-wave sweeps add in a fixed order.  So the fused sweep is taken out of the selection (sets with a bond > 32 run the ring
-  // sweep: 518 instead of 412 ms on the headline set) and the order in which workgroups pull pairs no longer matters.
+  // QK_DETERMINISTIC=1: bit-reproducible Grams.  By default the site-fused sweep sums the tiles of a column with LDS atomics in arrival
+  // order (two launches on the same inputs differ in the last bits, <= 9e-16); in this mode it takes its DET forms, which add in a fixed
+  // order (qk_fused.h: qkf_turn_add); the ring sweep, the small-bond sweep and the one-wave sweeps add in a fixed order anyway.  The order
+  // in which workgroups pull pairs never matters (a pair's result does not depend on the workgroup that sweeps it).
   if (const char* v = std::getenv("QK_DETERMINISTIC"))
-    if (std::atoi(v) != 0) c->fused_path = 0, c->deterministic = true;
+    if (std::atoi(v) != 0) c->deterministic = true;
   if (const char* v = std::getenv("QK_FUSED_SPLIT")) c->fused_split = std::atoi(v) != 0;
   if (const char* v = std::getenv("QK_FUSED_WGS")) c->fused_wgs = std::max(0, std::min(2, std::atoi(v)));
   if (const char* v = std::getenv("QK_WGS_PER_CU")) c->wgs_per_cu = std::max(1, std::min(4, std::atoi(v)));
@@ -828,13 +851,18 @@ extern "C" int qk_gram_values(qk_ctx* c, const qk_mps_set* xs, const qk_mps_set*
   // X: on the 60-qubit x 6-layer headline set (57 % of the work fits) the two shapes are within 2 % in time while the
   // smaller buffer moves 3.2 instead of 1.9 TB through the fabric -- so two workgroups only when >= 75 % of the padded
   // work fits.  A 16-row strip of X' must fit the buffer: bonds <= XCAP / 16.
-  const size_t lds_meta = 32 + (size_t)xs->n_sites * (48 + 16);  // queue slot, the overlap's accumulator, per-site records and tensor offsets
+  const bool det = c->deterministic;
+  const int turn_ints = det ? (ys->max_pad / TILE) * (xs->max_pad / TILE) : 0;  // DET forms: turn counters per set = blocks of b' x blocks of a' of the largest site
+  const size_t lds_meta = 16 + 256 + (size_t)xs->n_sites * (48 + 16) + (det ? (size_t)(2 * turn_ints + 2) * sizeof(int) : 0);  // queue slot, the overlap's accumulator, per-site records and tensor offsets, two sets of turn counters
   const bool fused_ok = c->variant == 20 && !f32 && !quad && c->fused_path != 0 && max_pad > (c->fused_path >= 2 ? 16 : 32);
   const bool can_one = max_pad <= QKF_XCAP_ONE / TILE && (size_t)QKF_XCAP_ONE * 16 + lds_meta <= 160 * 1024;
   const bool can_two = max_pad <= QKF_XCAP_TWO / TILE && (size_t)QKF_XCAP_TWO * 16 + lds_meta <= 80 * 1024;
   const bool fused = fused_ok && (can_one || can_two);
   // two runs of pairs, two shapes (see qk_plan_create): only when the launch is free to choose its shape
-  const bool two_runs = fused && can_one && can_two && c->fused_wgs == 0 && c->fused_split && !plan->second_wave2 && plan->n_first > 0 && plan->n_first < np;
+  // ... and the share is long enough: a short launch ends with a tail of its own (at a 1/8 share of the 60-qubit x 6-layer Gram, 61 pairs per
+  // CU: two launches 47.2 ms with 2.3 % of the sweep spent draining -- 1.5 % / 7.3 % of the two launches --, ONE launch of the 12-wave dual
+  // shape 47.1 ms with 0.6 %: profiles/r04/share_times_cfg4.txt), so below 100 pairs per CU the whole share is one launch
+  const bool two_runs = fused && can_one && can_two && c->fused_wgs == 0 && c->fused_split && !plan->second_wave2 && plan->n_first > 0 && plan->n_first < np && np >= 100ll * c->num_cus;
   // a mixed set: the plan's second run holds the pairs of two small states (every bond <= 32) for the one-wave sweep
   const bool mixed = fused && plan->second_wave2 && c->wave2_path && c->wave2_ring && plan->n_first > 0 && plan->n_first < np;
   // One class of pairs: the two-workgroup shape when the work sits in sites that fit its buffer AND most of it in sites of at most
@@ -865,12 +893,14 @@ extern "C" int qk_gram_values(qk_ctx* c, const qk_mps_set* xs, const qk_mps_set*
   a.scratch = c->scratch, a.x_plane = x_plane, a.t_plane = t_plane;
   a.xedge = a.yedge = nullptr, a.xedge_offs = a.yedge_offs = nullptr, a.edge_k = 0;
   a.xmg = a.ymg = nullptr, a.xmg_offs = a.ymg_offs = nullptr, a.merge_steps = 0;
+  a.turn_ints = turn_ints;
   a.counter = c->counter;
   a.nq = 1;  // kernels with XCD queues (site-fused, wave2) get the plan's queues below
   for (int s_ = 0; s_ <= QK_NQ_MAX; ++s_) a.qstart[s_] = plan->nq > 1 ? plan->qstart[s_] : (s_ == 0 ? 0 : np);
   // device clocks for the tail accounting, behind the queue heads: launch 1 uses [0] [1] [4], launch 2 [2] [3] [6]
   unsigned long long* const tail = c->counter + QK_NQ_MAX * QK_QSTRIDE;
   a.tail = tail;
+  a.err = tail + 7;
   a.prof = c->prof;
   a.debug_flags = 0, a.prio_mode = 0;
 #ifdef QK_LAB  // timing experiments of the lab kernels (they give wrong results by construction): libqklab.so only
@@ -981,16 +1011,16 @@ extern "C" int qk_gram_values(qk_ctx* c, const qk_mps_set* xs, const qk_mps_set*
         for (int s_ = 0; s_ <= 8; ++s_) a2.qstart[s_] = plan->qstart[8 + s_] - plan->n_first;
       }
       const unsigned g1 = (unsigned)std::min<long long>(a1.npairs, (long long)(fused_two ? 2 : 1) * c->num_cus);
-      if (fused_two) QKF_KERNEL_TWO<<<dim3(g1), dim3(64 * QKF_TWO_NW), lds_fused, c->stream>>>(a1);
-      else if (dual) QKF_KERNEL_DUAL<<<dim3(g1), dim3(64 * QKF_DUAL_NW), lds_fused, c->stream>>>(a1);
-      else QKF_KERNEL_ONE<<<dim3(g1), dim3(64 * QKF_ONE_NW), lds_fused, c->stream>>>(a1);
+      if (fused_two) QKF_LAUNCH_TWO(det, g1, lds_fused, a1);
+      else if (dual) QKF_LAUNCH_DUAL(det, g1, lds_fused, a1);
+      else QKF_LAUNCH_ONE(det, g1, lds_fused, a1);
       HIP_TRY(hipEventRecord(c->ev_mid, c->stream));
       qk_sweep_wave2_kernel<3, double><<<dim3((unsigned)std::min<long long>(a2.npairs, 8ll * c->num_cus)), dim3(64), 0, c->stream>>>(a2);
       c->last.second_pairs = plan->second.pairs, c->last.second_flops = plan->second.flops, c->last.second_padded_flops = plan->second.padded_flops;
       c->last.second_bytes = plan->second.bytes, c->last.second_kernel = QK_KERNEL_WAVE2;
       c->split_pending = true;
-    } else if (fused_two) QKF_KERNEL_TWO<<<dim3(grid), dim3(64 * QKF_TWO_NW), lds_fused, c->stream>>>(a);
-    else if (dual && !split) QKF_KERNEL_DUAL<<<dim3(grid), dim3(64 * QKF_DUAL_NW), lds_fused, c->stream>>>(a);
+    } else if (fused_two) QKF_LAUNCH_TWO(det, grid, lds_fused, a);
+    else if (dual && !split) QKF_LAUNCH_DUAL(det, grid, lds_fused, a);
     else if (split) {
       // the plan lists the pairs whose sites fit the smaller LDS buffer behind the others: one 12-wave workgroup per CU for
       // the first run, two 8-wave workgroups per CU for the second, back to back on the stream
@@ -1003,15 +1033,15 @@ extern "C" int qk_gram_values(qk_ctx* c, const qk_mps_set* xs, const qk_mps_set*
         a1.nq = a2.nq = 8;
         for (int s_ = 0; s_ <= 8; ++s_) a2.qstart[s_] = plan->qstart[8 + s_] - plan->n_first;
       }
-      if (dual) QKF_KERNEL_DUAL<<<dim3((unsigned)std::min<long long>(a1.npairs, c->num_cus)), dim3(64 * QKF_DUAL_NW), lds_fused, c->stream>>>(a1);
-      else QKF_KERNEL_ONE<<<dim3((unsigned)std::min<long long>(a1.npairs, c->num_cus)), dim3(64 * QKF_ONE_NW), lds_fused, c->stream>>>(a1);
+      if (dual) QKF_LAUNCH_DUAL(det, std::min<long long>(a1.npairs, c->num_cus), lds_fused, a1);
+      else QKF_LAUNCH_ONE(det, std::min<long long>(a1.npairs, c->num_cus), lds_fused, a1);
       HIP_TRY(hipEventRecord(c->ev_mid, c->stream));
-      QKF_KERNEL_TWO<<<dim3((unsigned)std::min<long long>(a2.npairs, 2ll * c->num_cus)), dim3(64 * QKF_TWO_NW), (size_t)QKF_XCAP_TWO * 16 + lds_meta, c->stream>>>(a2);
+      QKF_LAUNCH_TWO(det, std::min<long long>(a2.npairs, 2ll * c->num_cus), (size_t)QKF_XCAP_TWO * 16 + lds_meta, a2);
       c->last.second_pairs = plan->second.pairs, c->last.second_flops = plan->second.flops, c->last.second_padded_flops = plan->second.padded_flops;
-      c->last.second_bytes = plan->second.bytes, c->last.second_kernel = QK_KERNEL_FUSED2;
+      c->last.second_bytes = plan->second.bytes, c->last.second_kernel = det ? QK_KERNEL_FUSED2_DET : QK_KERNEL_FUSED2;
       c->split_pending = true;
-    } else QKF_KERNEL_ONE<<<dim3(grid), dim3(64 * QKF_ONE_NW), lds_fused, c->stream>>>(a);
-    c->last.kernel = fused_two ? QK_KERNEL_FUSED2 : dual ? QK_KERNEL_FUSED_DUAL : QK_KERNEL_FUSED1;
+    } else QKF_LAUNCH_ONE(det, grid, lds_fused, a);
+    c->last.kernel = fused_two ? (det ? QK_KERNEL_FUSED2_DET : QK_KERNEL_FUSED2) : dual ? (det ? QK_KERNEL_FUSED_DUAL_DET : QK_KERNEL_FUSED_DUAL) : (det ? QK_KERNEL_FUSED1_DET : QK_KERNEL_FUSED1);
   } else if (f32) {  // complex64 sweep: the ring kernel on fp32 planes; QK_VARIANT does not apply
     qk_sweep_ring_kernel<float><<<dim3(grid), dim3(512), lds_ring, c->stream>>>(a);
     c->last.kernel = QK_KERNEL_RING;
@@ -1066,12 +1096,15 @@ extern "C" const char* qk_kernel_name(int32_t kernel, int32_t precision) {
   switch (kernel) {
     case QK_KERNEL_WAVE: return "qk_sweep_wave_kernel<0>";
     case QK_KERNEL_SMALL: return f32 ? "qk_sweep_small_kernel<float>" : "qk_sweep_small_kernel<double>";
-    case QK_KERNEL_FUSED1: return "qk_sweep_fused_kernel<12, 2, 8192, 3>";
-    case QK_KERNEL_FUSED2: return "qk_sweep_fused_kernel<8, 1, 4608, 4>";
+    case QK_KERNEL_FUSED1: return "qk_sweep_fused_kernel<12, 2, 8192, 3, false>";
+    case QK_KERNEL_FUSED2: return "qk_sweep_fused_kernel<8, 1, 4608, 4, false>";
+    case QK_KERNEL_FUSED1_DET: return "qk_sweep_fused_kernel<12, 2, 8192, 3, true>";
+    case QK_KERNEL_FUSED2_DET: return "qk_sweep_fused_kernel<8, 1, 4608, 4, true>";
+    case QK_KERNEL_FUSED_DUAL_DET: return "qk_sweep_fused_dual_kernel<12, 8192, 3, true>";
     case QK_KERNEL_RING: return f32 ? "qk_sweep_ring_kernel<float>" : "qk_sweep_ring_kernel<double>";
     case QK_KERNEL_WAVE2: return precision == 32 ? "qk_sweep_wave2_kernel<3, float>" : "qk_sweep_wave2_kernel<3, double>";
     case QK_KERNEL_WAVE2_PLAIN: return "qk_sweep_wave2_kernel<0, double>";
-    case QK_KERNEL_FUSED_DUAL: return "qk_sweep_fused_dual_kernel<12, 8192, 3>";
+    case QK_KERNEL_FUSED_DUAL: return "qk_sweep_fused_dual_kernel<12, 8192, 3, false>";
     case QK_KERNEL_LAB: return "(lab kernel)";
     default: return "(none)";
   }
@@ -1097,6 +1130,7 @@ extern "C" int qk_get_stats(qk_ctx* c, qk_stats* out) {
       auto frac = [](const unsigned long long start, const unsigned long long first_exit, const unsigned long long last_exit) {
         return (last_exit > start && first_exit <= last_exit && first_exit >= start) ? (double)(last_exit - first_exit) / (double)(last_exit - start) : 0.0;
       };
+      if (t[7] != 0) return fail(QK_EDEVICE, "qk_get_stats: the ordered accumulation of the last sweep ran out of patience (a bug: please report); its results are not valid");
       c->last.tail_frac = frac(t[0], t[1], t[4]);
       if (c->split_pending) c->last.second_tail_frac = frac(t[2], t[3], t[6]);
       c->tail_pending = false;
@@ -1107,6 +1141,16 @@ extern "C" int qk_get_stats(qk_ctx* c, qk_stats* out) {
       c->split_pending = false;
     }
     c->ev_pending = false;
+#ifdef QKF_PROF  // experiment builds: the section sums of the launch(es) since the last call (wave cycles, all waves)
+    {
+      unsigned long long pf[8];
+      HIP_TRY(hipMemcpy(pf, c->prof, sizeof pf, hipMemcpyDeviceToHost));
+      HIP_TRY(hipMemset(c->prof, 0, sizeof pf));
+      const double tot = pf[7] > 0 ? (double)pf[7] : 1.0;
+      fprintf(stderr, "[qkf_prof] pair set-up %.3f  step set-up %.3f  phase1 %.3f  wait1 %.3f  phase2 %.3f  wait2 %.3f  tail %.3f  (of %.3e wave cycles)\n", pf[0] / tot, pf[1] / tot, pf[2] / tot,
+              pf[3] / tot, pf[4] / tot, pf[5] / tot, pf[6] / tot, tot);
+    }
+#endif
   }
   *out = c->last;
   return QK_OK;

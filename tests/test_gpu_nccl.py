@@ -103,6 +103,11 @@ def test_four_rank_bench_rehearsal(built, tmp_path):
     assert len(ms) == 4 and ms.min() > 0  # (four processes time-share ONE GPU here: their kernel times say nothing about balance)
     assert work.max() / work.min() < 1.02, work  # tiles dealt by cost, the lightest pair by pair: level shares of the padded work
     assert len(d["config"]["rank_tail_frac"]) == 4
+    # the cold Gram (fresh set, fresh plan -> K on the host) with its parts by rank: planning, the set's derived images, the first sweep, the all-gather
+    assert d["cold_step_ms"] > 0 and d["plan_ms"] > 0 and d["derive_ms"] > 0
+    for key in ("rank_cold_ms", "rank_plan_ms", "rank_job_setup_ms", "rank_derive_ms", "rank_cold_sweep_ms", "rank_allgather_ms"):
+        assert len(d["config"][key]) == 4 and min(d["config"][key]) >= 0, key
+    assert max(d["config"]["rank_cold_ms"]) <= d["cold_step_ms"] + 1e-6 and min(d["config"]["rank_allgather_ms"]) > 0
 
 
 @pytest.mark.timeout(600)
@@ -132,6 +137,10 @@ def test_bench_line_contract(built, tmp_path):
     assert rf["traffic"] is None and rf["traffic_source"].startswith("none")  # a reduced workload: no committed PMC summary to quote
     ls = rf["launches"]
     assert 1 <= len(ls) <= 2
+    # what the steady-state number hides and what binds: the cold Gram, the tile-reuse lower bound on the bytes, a roof per launch
+    assert d["cold_step_ms"] >= d["plan_ms"] > 0 and d["derive_ms"] > 0 and d["cold_over_steady"] > 0.9
+    assert 0 < rf["tile_reuse_gbytes"] < rf["algorithmic_gbytes_per_sweep"] and rf["matrix_pipe_frac"] is None
+    assert all(x["bound"] in ("mfma", "hbm", "fabric") for x in ls)
     assert abs(sum(x["kernel_ms"] for x in ls) - rf["kernel_ms"]) < 1e-6 * rf["kernel_ms"]
     assert abs(sum(x["algorithmic_tflop"] for x in ls) - rf["algorithmic_tflop_per_sweep"]) < 1e-9 * rf["algorithmic_tflop_per_sweep"]
     assert abs(rf["achieved"] - rf["algorithmic_tflop_per_sweep"] / (rf["kernel_ms"] * 1e-3)) < 1e-9 * rf["achieved"]

@@ -718,7 +718,7 @@ def test_one_class_sets_pick_their_shape_by_site_size(gpu_ctx):
 
     rng = np.random.default_rng(47)
     n = 14
-    for cap, want in ((48, "qk_sweep_fused_kernel<8, 1, 4608, 4>"), (64, "qk_sweep_fused_dual_kernel<12, 8192, 3>")):
+    for cap, want in ((48, "qk_sweep_fused_kernel<8, 1, 4608, 4, false>"), (64, "qk_sweep_fused_dual_kernel<12, 8192, 3, false>")):
         xs = [Q.random_mps(n, [min(2 ** min(k, n - k), cap) for k in range(n + 1)], rng) for _ in range(6)]
         K_ref = np.array([[abs(R.mps_inner(x.tensors, y.tensors)) ** 2 for x in xs] for y in xs])
         with gpu_ctx.upload(xs) as dx:
@@ -759,29 +759,44 @@ def test_complex64_storage_wave_sweep(gpu_ctx, monkeypatch):
 
 
 def test_deterministic_mode_is_bit_reproducible(built, monkeypatch):
-    """QK_DETERMINISTIC=1 takes the site-fused sweep (LDS atomics in arrival order) out of the selection: two Grams of the same
-    ragged set are bit-identical, launch after launch and context after context, and agree with the default path to rounding."""
+    """QK_DETERMINISTIC=1 switches the site-fused sweep to its DET forms: the contributions to a block of X' are added in a fixed
+    order (turn counters in LDS) instead of in arrival order.  Grams of the same ragged set are then bit-identical, launch after
+    launch and context after context, in every shape of the kernel -- the split sweep (12-wave dual shape + two workgroups per CU),
+    the single-tile 12-wave form, sites beyond the LDS buffer (strips), one class of small sites -- and agree with the oracle and
+    with the default (arrival-order) path to rounding."""
     import qml_cutensornet_amd as Q
     from oracle import restatement as R
     from qml_cutensornet_amd import engine
 
     rng = np.random.default_rng(41)
     n = 24
-    xs = [Q.random_mps(n, [min(2 ** min(k, n - k), c) for k in range(n + 1)], rng) for c in (90, 140, 40, 70, 33, 120, 64, 18)]
-    K_ref = R.gram_from_mps([m.tensors for m in xs])
-    with engine.context(0) as ctx, ctx.upload(xs) as dx:
-        K_default = ctx.gram(dx)
-        assert "fused" in ctx.stats()["kernel_name"]
-    monkeypatch.setenv("QK_DETERMINISTIC", "1")
-    runs = []
-    for _ in range(2):
+    cases = {
+        "split": [Q.random_mps(n, [min(2 ** min(k, n - k), c) for k in range(n + 1)], rng) for c in (90, 140, 40, 70, 33, 120, 64, 18)],
+        "small": [Q.random_mps(14, [min(2 ** min(k, 14 - k), 48) for k in range(15)], rng) for _ in range(6)],
+        "strips": [Q.random_mps(18, [min(2 ** min(k, 18 - k), c) for k in range(19)], rng) for c in (200, 150, 33, 97)],
+    }
+    for name, xs in cases.items():
+        K_ref = R.gram_from_mps([m.tensors for m in xs])
+        monkeypatch.delenv("QK_DETERMINISTIC", raising=False)
+        monkeypatch.delenv("QK_FUSED_DUAL", raising=False)
         with engine.context(0) as ctx, ctx.upload(xs) as dx:
-            runs.append(ctx.gram(dx))
-            runs.append(ctx.gram(dx))
-            assert "fused" not in ctx.stats()["kernel_name"]
-    for K in runs[1:]:
-        assert np.array_equal(K, runs[0])
-    assert np.abs(runs[0] - K_ref).max() < TOL and np.abs(runs[0] - K_default).max() < 1e-13
+            K_default = ctx.gram(dx)
+            assert "fused" in ctx.stats()["kernel_name"] and "true" not in ctx.stats()["kernel_name"]
+        monkeypatch.setenv("QK_DETERMINISTIC", "1")
+        for dual in (("1", "0") if name != "small" else ("1",)):
+            monkeypatch.setenv("QK_FUSED_DUAL", dual)
+            runs = []
+            for _ in range(2):
+                with engine.context(0) as ctx, ctx.upload(xs) as dx:
+                    runs.append(ctx.gram(dx))
+                    runs.append(ctx.gram(dx))
+                    st = ctx.stats()
+                    assert "fused" in st["kernel_name"] and st["kernel_name"].endswith("true>"), st["kernel_name"]
+                    if name == "split":
+                        assert st["second_kernel_name"] == "qk_sweep_fused_kernel<8, 1, 4608, 4, true>"
+            for K in runs[1:]:
+                assert np.array_equal(K, runs[0]), (name, dual)
+            assert np.abs(runs[0] - K_ref).max() < TOL and np.abs(runs[0] - K_default).max() < 1e-13, (name, dual)
 
 
 def test_mixed_set_keeps_small_pairs_on_the_one_wave_sweep(gpu_ctx, monkeypatch):
