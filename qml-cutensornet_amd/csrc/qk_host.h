@@ -46,7 +46,7 @@ struct qk_ctx {
   bool wave2_ring = true;  // ... with its k-step groups prefetched through a per-wave LDS ring (QK_WAVE2=2: plain loads)
   bool wave2_path = true;  // fp64 sets whose bonds are all <= 32 use the one-wave-per-pair sweep with 2 x 2 register tiles (QK_WAVE2=0 opts out)
   bool small_path = true;  // sets whose bonds are all <= 32 use the LDS-resident small-bond sweep (QK_SMALL=0 opts out)
-  bool fused_split = true;  // sweep the plan's two runs of pairs with the two shapes of the site-fused kernel (QK_FUSED_SPLIT=0: one shape)
+  int fused_split = 1;  // sweep the plan's two runs of pairs with the two shapes of the site-fused kernel: 1 = when the share is long enough for two launches (default), 2 = always, 0 = one shape (QK_FUSED_SPLIT)
   int fused_wgs = 0;       // workgroups per CU of the site-fused sweep: 0 = chosen per launch from the plan, 1 / 2 forced (QK_FUSED_WGS)
   bool deterministic = false;  // QK_DETERMINISTIC=1: only kernels that add in a fixed order (no LDS atomics)
   int fused_path = 1;      // fp64 sets with a bond > 32 use the site-fused sweep (QK_FUSED=0: ring sweep instead; 2: also for bonds 17..32)

@@ -12,7 +12,13 @@ int qk_fail(int code, const char* fmt, ...) __attribute__((format(printf, 2, 3))
 #ifndef QKF_XCAP_ONE_V
 #define QKF_XCAP_ONE_V 8192
 #endif
-static constexpr int QKF_XCAP_ONE = QKF_XCAP_ONE_V, QKF_XCAP_TWO = 4608;  // elements of the fused sweep's LDS X buffer with one / two workgroups per CU
+#ifndef QKF_XCAP_TWO_V
+#define QKF_XCAP_TWO_V 4608
+#endif
+#ifndef QKF_TWO_WGS
+#define QKF_TWO_WGS 2  // workgroups per CU of the small-site shape (experiment builds: 3 with a 3072-element buffer)
+#endif
+static constexpr int QKF_XCAP_ONE = QKF_XCAP_ONE_V, QKF_XCAP_TWO = QKF_XCAP_TWO_V;  // elements of the fused sweep's LDS X buffer with one / two workgroups per CU
 static constexpr int QK_TILE = 16;                                        // M/N granule of v_mfma_f64_16x16x4_f64
 static inline int qk_pad16(int x) { return (x + QK_TILE - 1) / QK_TILE * QK_TILE; }
 

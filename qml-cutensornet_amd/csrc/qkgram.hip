@@ -411,10 +411,10 @@ static int ctx_init(qk_ctx* c, int device_id, int num_cus) {
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(qk_sweep_small_kernel<double>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(qk_sweep_small_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(QKF_KERNEL_ONE), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(QKF_KERNEL_TWO), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(QKF_KERNEL_TWO), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 / QKF_TWO_WGS));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(QKF_KERNEL_DUAL), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(QKF_KERNEL_ONE_DET), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(QKF_KERNEL_TWO_DET), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(QKF_KERNEL_TWO_DET), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 / QKF_TWO_WGS));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(QKF_KERNEL_DUAL_DET), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
 #ifdef QK_LAB  // libqklab.so only: the experimental kernels of qk_lab.hip, selectable with QK_VARIANT
   {
@@ -434,7 +434,7 @@ static int ctx_init(qk_ctx* c, int device_id, int num_cus) {
   // in which workgroups pull pairs never matters (a pair's result does not depend on the workgroup that sweeps it).
   if (const char* v = std::getenv("QK_DETERMINISTIC"))
     if (std::atoi(v) != 0) c->deterministic = true;
-  if (const char* v = std::getenv("QK_FUSED_SPLIT")) c->fused_split = std::atoi(v) != 0;
+  if (const char* v = std::getenv("QK_FUSED_SPLIT")) c->fused_split = std::max(0, std::min(2, std::atoi(v)));
   if (const char* v = std::getenv("QK_FUSED_WGS")) c->fused_wgs = std::max(0, std::min(2, std::atoi(v)));
   if (const char* v = std::getenv("QK_WGS_PER_CU")) c->wgs_per_cu = std::max(1, std::min(4, std::atoi(v)));
   return QK_OK;
@@ -856,13 +856,13 @@ extern "C" int qk_gram_values(qk_ctx* c, const qk_mps_set* xs, const qk_mps_set*
   const size_t lds_meta = 16 + 256 + (size_t)xs->n_sites * (48 + 16) + (det ? (size_t)(2 * turn_ints + 2) * sizeof(int) : 0);  // queue slot, the overlap's accumulator, per-site records and tensor offsets, two sets of turn counters
   const bool fused_ok = c->variant == 20 && !f32 && !quad && c->fused_path != 0 && max_pad > (c->fused_path >= 2 ? 16 : 32);
   const bool can_one = max_pad <= QKF_XCAP_ONE / TILE && (size_t)QKF_XCAP_ONE * 16 + lds_meta <= 160 * 1024;
-  const bool can_two = max_pad <= QKF_XCAP_TWO / TILE && (size_t)QKF_XCAP_TWO * 16 + lds_meta <= 80 * 1024;
+  const bool can_two = max_pad <= QKF_XCAP_TWO / TILE && (size_t)QKF_XCAP_TWO * 16 + lds_meta <= 160 * 1024 / QKF_TWO_WGS;
   const bool fused = fused_ok && (can_one || can_two);
   // two runs of pairs, two shapes (see qk_plan_create): only when the launch is free to choose its shape
   // ... and the share is long enough: a short launch ends with a tail of its own (at a 1/8 share of the 60-qubit x 6-layer Gram, 61 pairs per
   // CU: two launches 47.2 ms with 2.3 % of the sweep spent draining -- 1.5 % / 7.3 % of the two launches --, ONE launch of the 12-wave dual
   // shape 47.1 ms with 0.6 %: profiles/r04/share_times_cfg4.txt), so below 100 pairs per CU the whole share is one launch
-  const bool two_runs = fused && can_one && can_two && c->fused_wgs == 0 && c->fused_split && !plan->second_wave2 && plan->n_first > 0 && plan->n_first < np && np >= 100ll * c->num_cus;
+  const bool two_runs = fused && can_one && can_two && c->fused_wgs == 0 && c->fused_split != 0 && !plan->second_wave2 && plan->n_first > 0 && plan->n_first < np && (c->fused_split == 2 || np >= 100ll * c->num_cus);
   // a mixed set: the plan's second run holds the pairs of two small states (every bond <= 32) for the one-wave sweep
   const bool mixed = fused && plan->second_wave2 && c->wave2_path && c->wave2_ring && plan->n_first > 0 && plan->n_first < np;
   // One class of pairs: the two-workgroup shape when the work sits in sites that fit its buffer AND most of it in sites of at most
@@ -870,7 +870,7 @@ extern "C" int qk_gram_values(qk_ctx* c, const qk_mps_set* xs, const qk_mps_set*
   // (uniform chains of bond 64, i.e. what a bond cap of 64 produces: dual against two workgroups measured in tools/uniform_ab.py)
   const bool fused_two = fused && can_two && !two_runs && (!can_one || c->fused_wgs == 2 || (c->fused_wgs == 0 && plan->fit_two >= 0.75 && plan->fit_narrow >= 0.5));
   const size_t lds_fused = (size_t)(fused_two ? QKF_XCAP_TWO : QKF_XCAP_ONE) * 16 + lds_meta;
-  const int grid = (int)std::min<long long>(units, (long long)(fused ? (fused_two ? 2 : 1) : c->wgs_per_cu) * c->num_cus);
+  const int grid = (int)std::min<long long>(units, (long long)(fused ? (fused_two ? QKF_TWO_WGS : 1) : c->wgs_per_cu) * c->num_cus);
   const char* dual_env = std::getenv("QK_FUSED_DUAL");
   // the 12-wave shape comes in two forms; the dual one (pairs of tiles per wave) is the default (QK_FUSED_DUAL=0: single tiles)
   const bool dual = fused && !fused_two && (dual_env ? std::atoi(dual_env) != 0 : true);
@@ -1010,7 +1010,7 @@ extern "C" int qk_gram_values(qk_ctx* c, const qk_mps_set* xs, const qk_mps_set*
         a1.nq = a2.nq = 8;
         for (int s_ = 0; s_ <= 8; ++s_) a2.qstart[s_] = plan->qstart[8 + s_] - plan->n_first;
       }
-      const unsigned g1 = (unsigned)std::min<long long>(a1.npairs, (long long)(fused_two ? 2 : 1) * c->num_cus);
+      const unsigned g1 = (unsigned)std::min<long long>(a1.npairs, (long long)(fused_two ? QKF_TWO_WGS : 1) * c->num_cus);
       if (fused_two) QKF_LAUNCH_TWO(det, g1, lds_fused, a1);
       else if (dual) QKF_LAUNCH_DUAL(det, g1, lds_fused, a1);
       else QKF_LAUNCH_ONE(det, g1, lds_fused, a1);
@@ -1036,7 +1036,7 @@ extern "C" int qk_gram_values(qk_ctx* c, const qk_mps_set* xs, const qk_mps_set*
       if (dual) QKF_LAUNCH_DUAL(det, std::min<long long>(a1.npairs, c->num_cus), lds_fused, a1);
       else QKF_LAUNCH_ONE(det, std::min<long long>(a1.npairs, c->num_cus), lds_fused, a1);
       HIP_TRY(hipEventRecord(c->ev_mid, c->stream));
-      QKF_LAUNCH_TWO(det, std::min<long long>(a2.npairs, 2ll * c->num_cus), (size_t)QKF_XCAP_TWO * 16 + lds_meta, a2);
+      QKF_LAUNCH_TWO(det, std::min<long long>(a2.npairs, (long long)QKF_TWO_WGS * c->num_cus), (size_t)QKF_XCAP_TWO * 16 + lds_meta, a2);
       c->last.second_pairs = plan->second.pairs, c->last.second_flops = plan->second.flops, c->last.second_padded_flops = plan->second.padded_flops;
       c->last.second_bytes = plan->second.bytes, c->last.second_kernel = det ? QK_KERNEL_FUSED2_DET : QK_KERNEL_FUSED2;
       c->split_pending = true;

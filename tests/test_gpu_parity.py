@@ -586,6 +586,32 @@ def test_cfg5_real_states(gpu_ctx, monkeypatch):
             assert name in ctx_other.stats()["kernel_name"]
 
 
+def test_complex64_on_the_real_states_of_cfg5_and_cfg4(gpu_ctx):
+    """The fp32 leg of cfg5's "fp32 vs fp64 tolerance sweep" (BASELINE.json configs[4]; the reference never sets float_precision, ref
+    gpu_backend/kernel_state_ansatz.py:141-144) on the config's REAL states, and on cfg4's.  cfg5 (bonds <= 32): complex64 STORAGE with
+    fp64 arithmetic (qk_sweep_wave2_kernel<3, float>) is the fp64 sweep of the rounded tensors -- checked against the oracle ON the
+    rounded tensors to 1e-11 -- and differs from the exact Gram by the input rounding only.  cfg4 (bonds to 248): complex64 ARITHMETIC on
+    the fp32 matrix cores (ring sweep), within the complex64 tolerance of the fp64 Gram.  The table of both over n and chi:
+    tools/fp32_sweep.py -> profiles/r04/fp32_tolerance.txt."""
+    from oracle import c_oracle
+
+    for (n, reps, d, gamma, pts), want in (((100, 10, 4, 0.1, 8), "qk_sweep_wave2_kernel<3, float>"), ((60, 6, 2, 1.0, 6), "qk_sweep_ring_kernel<float>")):
+        states = _real_states(n, reps, d, gamma, pts)
+        rounded = [[t.astype(np.complex64).astype(np.complex128) for t in m.tensors] for m in states]
+        pairs = np.array([(i, j) for j in range(pts) for i in range(pts)], dtype=np.int32)
+        _, z_round, _ = c_oracle.gram_pairs(rounded, None, pairs)
+        _, z_exact, _ = c_oracle.gram_pairs([m.tensors for m in states], None, pairs)
+        z_round, z_exact = z_round.reshape(pts, pts), z_exact.reshape(pts, pts)
+        with gpu_ctx.upload(states) as d64, d64.to_f32() as d32:
+            z32 = gpu_ctx.overlaps(d32)
+            assert gpu_ctx.stats()["kernel_name"] == want
+            K32, K64 = gpu_ctx.gram(d32), gpu_ctx.gram(d64)
+        if "wave2" in want:
+            assert np.abs(z32 - z_round).max() < TOL  # fp64 arithmetic on rounded inputs: exact to fp64 accuracy
+        assert np.abs(z32 - z_exact).max() < F32_TOL and np.abs(K32 - K64).max() < F32_TOL
+        assert np.abs(np.diag(K32) - 1).max() < F32_TOL and np.array_equal(K32, K32.T)
+
+
 def test_both_contraction_orders_agree(gpu_ctx):
     """X1: <x_i|x_j> contracted with x_j as the Y state (the order QK_PLAN_ORIENT may pick) and with x_i as the Y state give
     conjugate overlaps to 1e-13 -- on ragged states where the two orders do different amounts of padded work."""
@@ -697,9 +723,10 @@ def test_split_sweep_two_shapes_one_gram(gpu_ctx, monkeypatch):
     caps = [40, 48, 56, 60, 150, 120, 100, 64]
     xs = [Q.random_mps(n, [min(2 ** min(k, n - k), c) for k in range(n + 1)], rng) for c in caps]
     K_ref = np.array([[abs(R.mps_inner(x.tensors, y.tensors)) ** 2 for x in xs] for y in xs])
-    with gpu_ctx.upload(xs) as dx:
-        K = gpu_ctx.gram(dx)
-        st = gpu_ctx.stats()
+    monkeypatch.setenv("QK_FUSED_SPLIT", "2")  # (a share of fewer than 100 pairs per CU is ONE launch by default: its second launch would be mostly tail)
+    with engine.context(0) as ctx2, ctx2.upload(xs) as dx:
+        K = ctx2.gram(dx)
+        st = ctx2.stats()
         assert st["kernel_name"].startswith("qk_sweep_fused_dual_kernel<12") and st["second_kernel_name"].startswith("qk_sweep_fused_kernel<8")
         assert 0 < st["second_pairs"] < st["pairs"] and 0 < st["second_ms"] < st["kernel_ms"] and 0 < st["second_flops"] < st["flops"]
     monkeypatch.setenv("QK_FUSED_SPLIT", "0")
@@ -783,6 +810,7 @@ def test_deterministic_mode_is_bit_reproducible(built, monkeypatch):
             K_default = ctx.gram(dx)
             assert "fused" in ctx.stats()["kernel_name"] and "true" not in ctx.stats()["kernel_name"]
         monkeypatch.setenv("QK_DETERMINISTIC", "1")
+        monkeypatch.setenv("QK_FUSED_SPLIT", "2" if name == "split" else "1")  # (short shares are one launch by default)
         for dual in (("1", "0") if name != "small" else ("1",)):
             monkeypatch.setenv("QK_FUSED_DUAL", dual)
             runs = []

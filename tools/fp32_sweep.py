@@ -40,6 +40,20 @@ def main():
             k64, k32 = ctx.gram(d64), ctx.gram(d32)
         dk = np.abs(k32 - k64)
         print(f"{n:6d} {reps:5d} {gamma:6.1f} {max(m.max_bond() for m in states):8d} {dk.max():10.2e} {np.median(dk):10.2e} {np.abs(np.diag(k32) - 1).max():12.2e}")
+    # the real states of the configs (first points of each config's own data set, host builder): what cfg5's "fp32 vs fp64 tolerance sweep" asks for
+    print("real states of the configs (seed 5, truncation 1e-16): complex64 sets against complex128")
+    print(f"{'config':>22} {'points':>6} {'chi max':>8} {'kernel (complex64)':>34} {'max|dK|':>10} {'med|dK|':>10} {'max|diag-1|':>12} {'min K64':>10}")
+    from qml_cutensornet_amd.builder_pool import build_states
+
+    for name, n, reps, d, gamma, full, pts in (("cfg3 40q x 4, d=2, g=1", 40, 4, 2, 1.0, 200, 24), ("cfg4 60q x 6, d=2, g=1", 60, 6, 2, 1.0, 500, 24), ("cfg5 100q x 10, d=4, g=.1", 100, 10, 4, 0.1, 1000, 32)):
+        X = synthetic_features(full, n, 5)[:pts]
+        ans = Q.KernelStateAnsatz(n, reps, gamma, Q.entanglement_graph(n, d))
+        states, _ = build_states(ans, X, 1 - 1e-16, min(pts, os.cpu_count() or 1))
+        with ctx.upload(states) as d64, d64.to_f32() as d32:
+            k64, k32 = ctx.gram(d64), ctx.gram(d32)
+            kern = ctx.stats()["kernel_name"]
+        dk = np.abs(k32 - k64)
+        print(f"{name:>22} {pts:6d} {max(m.max_bond() for m in states):8d} {kern:>34} {dk.max():10.2e} {np.median(dk):10.2e} {np.abs(np.diag(k32) - 1).max():12.2e} {k64.min():10.2e}")
     ctx.close()
 
 
