@@ -146,7 +146,8 @@ def quoted_traffic(cfg_name, kernels):
         ent = next((v for name, v in pmc.get("kernels", {}).items() if k and k in name), None)
         if ent is None or "traffic_bytes_per_launch" not in ent:
             return None, f"the summary has no entry for {k}"
-        out[k] = (ent["traffic_bytes_per_launch"], ent.get("mfma_flops_executed"))  # (bytes, flops the matrix cores executed: SQ_INSTS_VALU_MFMA_MOPS_F64)
+        out[k] = (ent["traffic_bytes_per_launch"], ent.get("mfma_flops_executed"),  # (bytes, flops the matrix cores executed: SQ_INSTS_VALU_MFMA_MOPS_F64,
+                  {q_: ent[q_] for q_ in ("l2_hit_rate", "lds_active_share_of_busy", "lds_bank_conflict_share_of_lds_active", "mfma_util") if ent.get(q_) is not None})  # other quoted counters)
     return out, os.path.relpath(pmc_file, ROOT)
 
 
@@ -456,12 +457,13 @@ def main():
             per_kernel, traffic_src = quoted_traffic(cfg_dir, [ln["kernel"] for ln in launches])
             if per_kernel:
                 for ln in launches:
-                    ln["traffic_bytes"], ex = per_kernel[ln["kernel"]]
+                    ln["traffic_bytes"], ex, more = per_kernel[ln["kernel"]]
+                    ln.update({f"pmc_{k_}": v_ for k_, v_ in more.items()})  # L2 hit rate, LDS shares, matrix-pipe busy under the profiler
                     if ex:  # what the matrix cores executed (3M complex product, k-steps trimmed to the true bonds, edge blocks, merged steps)
                         ln["executed_mfma_tflop"] = ex / 1e12
                         ln["executed_over_algorithmic_4m"] = ex * 4.0 / 3.0 / (ln["algorithmic_tflop"] * 1e12) if ln["algorithmic_tflop"] > 0 else None
-                traffic = float(sum(b for b, _ in per_kernel.values()))
-                executed = sum(e for _, e in per_kernel.values() if e) if all(e for _, e in per_kernel.values()) else None
+                traffic = float(sum(v_[0] for v_ in per_kernel.values()))
+                executed = sum(v_[1] for v_ in per_kernel.values() if v_[1]) if all(v_[1] for v_ in per_kernel.values()) else None
                 for ln in launches:  # what binds THIS launch, from the measured resources
                     ln["traffic_tb_per_s"] = ln["traffic_bytes"] / (ln["kernel_ms"] * 1e-3) / 1e12 if ln["kernel_ms"] > 0 else None
                     if ln.get("executed_mfma_tflop"):  # share of the launch during which the matrix pipes would be busy at peak clock: executed flops / time / peak

@@ -38,7 +38,7 @@ def main():
             if needle in r["Name"]:
                 avg_ms[r["Name"]] = float(r["AverageNs"]) / 1e6
     kernels = {}
-    for tag in ("fetch", "write", "sq"):
+    for tag in ("fetch", "write", "sq", "lds", "tcc"):
         p = os.path.join(src, f"pmc_{tag}", "pmc_counter_collection.csv")
         if not os.path.exists(p):
             continue
@@ -73,6 +73,17 @@ def main():
             sq = raw["pmc_sq"]
             if sq.get("SQ_BUSY_CU_CYCLES"):
                 ent["mfma_busy_share_of_cu_busy"] = sq.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / sq["SQ_BUSY_CU_CYCLES"] / 4.0  # four SIMDs per CU
+        if "pmc_lds" in raw and raw["pmc_lds"].get("SQ_BUSY_CYCLES"):
+            ld = raw["pmc_lds"]
+            # SQ_LDS_IDX_ACTIVE = cycles the LDS array works for indexed ops, SQ_LDS_BANK_CONFLICT = the extra cycles of conflicts (MI355X_MICROARCH.md, LDS);
+            # both summed over the CUs like SQ_BUSY_CYCLES; SQ_WAIT_INST_LDS in quad-cycles of waves, against SQ_WAVE_CYCLES
+            ent["lds_active_share_of_busy"] = ld.get("SQ_LDS_IDX_ACTIVE", 0.0) / ld["SQ_BUSY_CYCLES"]
+            ent["lds_bank_conflict_share_of_lds_active"] = ld.get("SQ_LDS_BANK_CONFLICT", 0.0) / ld["SQ_LDS_IDX_ACTIVE"] if ld.get("SQ_LDS_IDX_ACTIVE") else None
+            ent["wave_share_waiting_to_issue_lds"] = ld.get("SQ_WAIT_INST_LDS", 0.0) / ld["SQ_WAVE_CYCLES"] if ld.get("SQ_WAVE_CYCLES") else None
+            ent["lds_instructions_per_launch"] = ld.get("SQ_INSTS_LDS")
+        if "pmc_tcc" in raw and (raw["pmc_tcc"].get("TCC_HIT_sum", 0.0) + raw["pmc_tcc"].get("TCC_MISS_sum", 0.0)) > 0:
+            tc = raw["pmc_tcc"]
+            ent["l2_hit_rate"] = tc["TCC_HIT_sum"] / (tc["TCC_HIT_sum"] + tc["TCC_MISS_sum"])
     # roctx ranges of the marker-trace run: one line per range name
     mk = glob.glob(os.path.join(src, "marker", "**", "*marker_api_trace.csv"), recursive=True)
     if mk:

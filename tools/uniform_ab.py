@@ -11,6 +11,9 @@ os.environ.update(QK_FUSED="2", QK_WAVE="0", QK_WAVE2="0", QK_SMALL="0")
 import qml_cutensornet_amd as Q  # noqa: E402
 from qml_cutensornet_amd import engine  # noqa: E402
 
+if os.environ.get("QK_AB_LIB"):  # another build of the library (build_variant) on the same box
+    engine.LIB_PATH = os.path.abspath(os.environ["QK_AB_LIB"])
+
 
 def main():
     caps = [int(c) for c in sys.argv[1].split(",")]
