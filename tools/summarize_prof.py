@@ -77,7 +77,8 @@ def main():
             ld = raw["pmc_lds"]
             # SQ_LDS_IDX_ACTIVE = cycles the LDS array works for indexed ops, SQ_LDS_BANK_CONFLICT = the extra cycles of conflicts (MI355X_MICROARCH.md, LDS);
             # both summed over the CUs like SQ_BUSY_CYCLES; SQ_WAIT_INST_LDS in quad-cycles of waves, against SQ_WAVE_CYCLES
-            ent["lds_active_share_of_busy"] = ld.get("SQ_LDS_IDX_ACTIVE", 0.0) / ld["SQ_BUSY_CYCLES"]
+            # (SQ_BUSY_CYCLES comes back summed over the 32 shader engines, the LDS counters over the 256 CUs: 8 CUs per engine)
+            ent["lds_active_share_of_busy"] = ld.get("SQ_LDS_IDX_ACTIVE", 0.0) / ld["SQ_BUSY_CYCLES"] / 8.0
             ent["lds_bank_conflict_share_of_lds_active"] = ld.get("SQ_LDS_BANK_CONFLICT", 0.0) / ld["SQ_LDS_IDX_ACTIVE"] if ld.get("SQ_LDS_IDX_ACTIVE") else None
             ent["wave_share_waiting_to_issue_lds"] = ld.get("SQ_WAIT_INST_LDS", 0.0) / ld["SQ_WAVE_CYCLES"] if ld.get("SQ_WAVE_CYCLES") else None
             ent["lds_instructions_per_launch"] = ld.get("SQ_INSTS_LDS")
