@@ -405,6 +405,17 @@ def main():
     kms = float(np.mean(kernel_ms)) if kernel_ms else float("nan")
     kernel_name = kernel_name or ctx.stats()["kernel_name"]
 
+    # the cold Gram through the C ABI's one-call route (qk_gram_host: what build_kernel_matrix runs on one rank, gpu_backend/kernel_state_ansatz.py):
+    # a fresh set again -- fresh plan, fresh derived images, its own buffers -> K in host memory; rank 0, after the timed region
+    cold_abi = None
+    if world == 1 and states is not None:
+        x2 = ctx.upload(states) if args.precision == "f64" else None
+        if x2 is not None:
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            K2 = ctx.gram(x2)
+            cold_abi = {"ms": 1e3 * (time.perf_counter() - t0), "max_abs_vs_steady": float(np.abs(K2 - host_K.numpy()).max())}
+            x2.close()
     # sanity on the result itself (invariants of a Gram of normalised states)
     Kh = host_K.numpy()
     diag_err = float(np.abs(np.diag(Kh) - 1).max())
@@ -493,6 +504,7 @@ def main():
             "cold_over_steady": cold["cold_step_ms"] / ms_per_step if ms_per_step > 0 else None,
             "plan_ms": cold["plan_ms"],
             "derive_ms": cold["derive_ms"],
+            "cold_c_abi_ms": cold_abi["ms"] if cold_abi else None,  # the same through qk_gram_host alone (no torch): the product's one-rank route
             "dtype": "f64 (complex128)" if args.precision == "f64" else "f32 (complex64)",
             "data": "synthetic features (normal -> standardise -> MinMax[0,2], seed %d); real ansatz MPS built %s" % (args.seed, f"on the device, bonds cut at {args.max_bond}" if args.max_bond else "on the host"),
             "config": {
@@ -522,6 +534,7 @@ def main():
                 "rank_allgather_ms": [round(float(v), 3) for v in (steady_gather_ms if isinstance(steady_gather_ms, list) else [steady_gather_ms])],
                 "plan_threads": int(cold["plan_threads"]),
                 "host_cpu": _host_cpu(),
+                **({"cold_c_abi_vs_steady_max_abs": cold_abi["max_abs_vs_steady"]} if cold_abi else {}),
                 **({"f32_vs_f64_max_abs": float(np.abs(Kh - k64_ref).max()), "f32_vs_f64_median_abs": float(np.median(np.abs(Kh - k64_ref)))} if k64_ref is not None else {}),
                 **({"device_built_vs_host_built_gram_max_abs": float(np.abs(K_dev - Kh).max())} if K_dev is not None else {}),
             },
