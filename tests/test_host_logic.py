@@ -686,3 +686,36 @@ def test_plan_is_independent_of_the_thread_count_and_create_all_equals_create(bu
     assert [snapshot(p) for p in plans] == ref
     for p in plans:
         p.close()
+
+
+def test_bench_quotes_pmc_figures_only_for_the_sources_they_were_taken_on(monkeypatch):
+    """bench.py's `roofline.traffic` / `matrix_pipe_frac` / L2 hit rate are QUOTED from the committed rocprofv3 summaries
+    (profiles/<round>/<config>/pmc_summary.json): only while the digest of the sweep sources recorded there equals this build's --
+    a stale summary is named as such and nothing is quoted."""
+    import json
+    import os
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import bench
+
+    found = None
+    for rnd in bench.PROFILE_ROUNDS:
+        f = os.path.join(root, "profiles", rnd, "cfg4", "pmc_summary.json")
+        if os.path.exists(f):
+            found = json.load(open(f))
+            break
+    assert found is not None and found["source_sha"] and found["kernels"]
+    names = [k.split("void ")[-1].split("(")[0] for k in found["kernels"]]
+    monkeypatch.setattr(bench, "sweep_source_sha", lambda: found["source_sha"])
+    per_kernel, src = bench.quoted_traffic("cfg4", names)
+    assert per_kernel is not None and src.endswith("pmc_summary.json")
+    for k in names:
+        traffic, executed, more = per_kernel[k]
+        assert traffic > 0 and executed > 0 and 0 < more["l2_hit_rate"] < 1 and 0 < more["mfma_util"] < 1
+    monkeypatch.setattr(bench, "sweep_source_sha", lambda: "0" * 16)
+    per_kernel, why = bench.quoted_traffic("cfg4", names)
+    assert per_kernel is None and "stale" in why
+    per_kernel, why = bench.quoted_traffic("no_such_config", names)
+    assert per_kernel is None and "no committed summary" in why
