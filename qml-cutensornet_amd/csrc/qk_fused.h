@@ -38,6 +38,8 @@
 // while most of the work sits in sites that fit the smaller buffer.  A wave issues in order, so its tails, set-up and load waits
 // stall its own matrix stream: the more waves share a SIMD, the better the matrix pipe is fed (8 waves x 4 slots: 482 ms
 // on the headline set, 12 x 2: 452 ms, 16 x 1: 455 ms with a few spilled registers).
+// Both kernels come in a DET form (template parameter; QK_DETERMINISTIC=1): the contributions to a block of X' are then added in a fixed
+// order (qkf_turn_add) and a Gram is bit-reproducible, at 1.03 x the time on the headline set.
 // fp64 only: the f32 MFMA's C layout (C[4q + r][j]) is not an operand layout (the complex64 sweep stays on qk_ring.h).
 #pragma once
 #include "qk_device.h"

@@ -10,10 +10,12 @@
 // (v_mfma_f64_16x16x4_f64), and finally writes |<x|y>|^2.
 //
 //
-// Files: this one = C ABI (include/qkgram.h), packing, planner, small kernels, launches;  qk_fused.h = the site-fused
-// sweep (the fp64 hot path) and the 2 x 2-tile one-wave sweep (fp64, bonds <= 32);  qk_ring.h = the ring sweep (complex64,
-// very large bonds), the LDS-resident small-bond sweep and the one-tile one-wave sweep;  qk_build.hip = the device MPS builder.  lab/qk_lab.hip (experimental / diagnostic kernels) is NOT part of
-// libqkgram.so: it is linked only into libqklab.so (-DQK_LAB), which tools/ load for A/B measurements.
+// Files: this one = C ABI (include/qkgram.h), packing, the kernels that make a set's derived images (interleaved tensors, edge blocks,
+// merged steps), small kernels, launches;  qk_planner.cpp = the host planner (plain C++);  qk_fused.h = the site-fused sweep (the fp64 hot
+// path, plain and DET forms) and the 2 x 2-tile one-wave sweep (fp64, bonds <= 32);  qk_ring.h = the ring sweep (complex64, very large
+// bonds), the LDS-resident small-bond sweep and the one-tile one-wave sweep;  qk_build.hip = the device MPS builder;  qk_comm.hip = the
+// multi-GPU entry points.  lab/qk_lab.hip (experimental / diagnostic kernels) is NOT part of libqkgram.so: it is linked only into
+// libqklab.so (-DQK_LAB), which lab/tools load for A/B measurements.
 // Written for gfx950 only: 64-lane wavefronts, 160 KiB LDS per CU, no portability layer.
 #include "qk_host.h"
 #include "qk_ring.h"
