@@ -9,11 +9,13 @@ import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import __graft_entry__ as graft
-
-graft.build()
 import qml_cutensornet_amd as Q
-from oracle import c_oracle
 from qml_cutensornet_amd import engine
+
+if os.environ.get("QK_AB_LIB"):  # another build of the library (lab/libqkgram_<variant>.so): before build() loads the shipped one
+    engine.LIB_PATH = os.path.abspath(os.environ["QK_AB_LIB"])
+graft.build()
+from oracle import c_oracle
 
 
 def main():
