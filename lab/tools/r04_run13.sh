@@ -1,0 +1,14 @@
+#!/bin/bash
+mkdir -p gpurun_out
+export QK_CACHE_DIR=/tmp/qkc
+O=gpurun_out/exp13.txt
+: > $O
+run() { echo "== $*" >> $O; timeout -k 10 500 "$@" >> $O 2>&1 || { echo "FAILED rc $?" >> $O; tail -20 $O; exit 1; }; }
+QK_AB_LIB=lab/libqkgram_gp.so timeout -k 10 300 python lab/tools/fuzz_split.py 20 > gpurun_out/fuzz_gp.log 2>&1 || { echo "fuzz gp FAILED"; tail -20 gpurun_out/fuzz_gp.log; exit 1; }
+echo "fuzz gp: $(tail -1 gpurun_out/fuzz_gp.log | cut -c1-40)" >> $O
+for v in base gauss gp base gauss gp; do
+  export QK_AB_LIB=lab/libqkgram_$v.so
+  run python tools/ab_plan.py cfg4 3 QK_PLAN_TILE=8
+done
+unset QK_AB_LIB
+grep -E "^fuzz|kernel |library" $O | cut -c1-110 | sed 's/QK_PLAN_TILE=8 *//'

@@ -118,8 +118,28 @@ __device__ __forceinline__ void qkf_p1_tile(QkfTile& t, v2d (&fr)[4], const bool
   for (int i = 0; i < 4; ++i) fx[i] = qkf_ldx(xp + i * xstep, xoff);
   const int ng = (nks + 3) >> 2, last = nks - 4 * (ng - 1);  // k-steps of the last group: 1..4
   QKF_PRIO_LO();
+  int gq = 0;
+  // the first k-step of a chain of more than four k-steps STARTS the accumulators (literal zero as the C operand): no register moves to zero
+  // them -- on gfx950 every vector instruction takes time from the matrix pipe (lab/tools/mfma_rate.hip)
+  if (ng >= 2) {
+    gq = 1;
+    cur.off += 4 * cur.step, xoff += 4 * xstep;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      if (i == 0) {
+        const v4d z = {0, 0, 0, 0};
+        p1 = __builtin_amdgcn_mfma_f64_16x16x4f64(fx[0].x, fr[0].x, z, 0, 0, 0);
+        p2 = __builtin_amdgcn_mfma_f64_16x16x4f64(fx[0].y, fr[0].y, z, 0, 0, 0);
+        p3 = __builtin_amdgcn_mfma_f64_16x16x4f64(fx[0].x + fx[0].y, fr[0].x + fr[0].y, z, 0, 0, 0);
+      } else {
+        qkf_kstep<false>(p1, p2, p3, fx[i].x, fx[i].y, fr[i].x, fr[i].y);
+      }
+      fr[i] = qkf_ldg_b(cur.base + i * cur.step, cur.off), fx[i] = qkf_ldx(xp + i * xstep, xoff);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
 #pragma unroll 1
-  for (int gq = 0; gq + 1 < ng; ++gq) {
+  for (; gq + 1 < ng; ++gq) {
     cur.off += 4 * cur.step, xoff += 4 * xstep;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -643,8 +663,36 @@ __device__ __forceinline__ void qkf_p1_dual(QkfTile& t0, QkfTile& t1, v2d (&fr)[
   for (int i = 0; i < 4; ++i) fx[i] = qkf_ldx(xp + i * xstep, xoff);
   const int ng = (nks + 3) >> 2, last = nks - 4 * (ng - 1);  // k-steps of the last group: 1..4
   QKF_PRIO_LO();
+  int gq = 0;
+  // (the first k-step of a chain of more than four k-steps STARTS the accumulators -- literal zero as the C operand --: no register moves to zero them)
+  if (ng >= 2) {
+    gq = 1;
+    cur.off += 4 * cur.step, xoff += 4 * xstep;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      if (i == 0) {
+        const v4d z = {0, 0, 0, 0};
+        const double sa = fx[0].x + fx[0].y;
+        p1 = __builtin_amdgcn_mfma_f64_16x16x4f64(fx[0].x, fr[0].x, z, 0, 0, 0);
+        p2 = __builtin_amdgcn_mfma_f64_16x16x4f64(fx[0].y, fr[0].y, z, 0, 0, 0);
+        p3 = __builtin_amdgcn_mfma_f64_16x16x4f64(sa, fr[0].x + fr[0].y, z, 0, 0, 0);
+        if (HAS1) {
+          r1 = __builtin_amdgcn_mfma_f64_16x16x4f64(fx[0].x, fs[0].x, z, 0, 0, 0);
+          r2 = __builtin_amdgcn_mfma_f64_16x16x4f64(fx[0].y, fs[0].y, z, 0, 0, 0);
+          r3 = __builtin_amdgcn_mfma_f64_16x16x4f64(sa, fs[0].x + fs[0].y, z, 0, 0, 0);
+        }
+      } else {
+        qkf_kstep<false>(p1, p2, p3, fx[i].x, fx[i].y, fr[i].x, fr[i].y);
+        if (HAS1) qkf_kstep<false>(r1, r2, r3, fx[i].x, fx[i].y, fs[i].x, fs[i].y);
+      }
+      fr[i] = qkf_ldg_b(cur.base + i * cur.step, cur.off);
+      if (HAS1) fs[i] = qkf_ldg_b(cur.base + i * cur.step, cur.off + TILE);
+      fx[i] = qkf_ldx(xp + i * xstep, xoff);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
 #pragma unroll 1
-  for (int gq = 0; gq + 1 < ng; ++gq) {
+  for (; gq + 1 < ng; ++gq) {
     cur.off += 4 * cur.step, xoff += 4 * xstep;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -672,8 +720,62 @@ __device__ __forceinline__ void qkf_p1_dual(QkfTile& t0, QkfTile& t1, v2d (&fr)[
 
 // Phase 2 of a pair of tiles: X'[tb0 rows | tb0 + 1 rows, tn cols] += T0^T | T1^T conj(A[16 ta + ., p, 16 tn + .]).  `nxt` is the
 // wave's next phase-1 stream (NXT_P1: both column blocks are loaded, the second one at + n1 elements) or a dummy.
-template <bool FULL, bool HAS1, bool DET = false>
-__device__ __forceinline__ void qkf_p2_dual(const QkfTile& t0, const QkfTile& t1, v2d (&fr)[4], v2d (&fs)[4], QkfStream cur, const int a2, const int nn, const int kmax, lds_v2d* xo, const int q,
+// On gfx950 a vector-ALU instruction is not free beside the fp64 matrix instructions: whichever wave of the SIMD issues it, it takes 6 - 9
+// cycles that the matrix pipe then stands still (lab/tools/mfma_rate.hip: 64.6 cycles per v_mfma_f64_16x16x4_f64 alone, + 6.6 per 32-bit and
+// + 9.2 per 64-bit instruction put between them at two waves per SIMD).  So the loop over the column blocks is written for FEW instructions:
+// the sums re + im of the T tiles' k-steps are taken once per unit, not once per block; the loop runs over the blocks that are followed by
+// another block of this stream -- the four k-steps' addresses are then a lane offset on four wave-uniform bases that do not change -- and the
+// last block, which reloads the registers with the first group of `nxt`, stands behind it; the product's second 3M form saves a third of
+// the additions behind a block.  cfg4, one box, step by step: 374.4 -> 370.6 (this loop) -> 368.0 (3M form) -> 364.3 (phase 1 started by its
+// first k-step) -> 363.9 ms (the same in the one-tile kernel).
+typedef __attribute__((address_space(3))) double lds_double;
+// one column block: the matrix instructions of the k-steps in `fr`, each followed by the reload of its registers from (b_i, off), then the
+// results added to X' at d (and d1 for the second tile)
+template <bool FULL, bool HAS1>
+__device__ __forceinline__ void qkf_p2_block(const QkfTile& t0, const QkfTile& t1, const v4d& s0, const v4d& s1, v2d (&fr)[4], const int kmax, const v2d* const b0, const v2d* const b1,
+                                             const v2d* const b2, const v2d* const b3, const unsigned off, lds_double* const d, lds_double* const d1, const long rs) {
+  v4d p1 = {0, 0, 0, 0}, p2 = {0, 0, 0, 0}, p3 = {0, 0, 0, 0}, r1 = {0, 0, 0, 0}, r2 = {0, 0, 0, 0}, r3 = {0, 0, 0, 0};
+  QKF_PRIO_LO();
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    if (FULL || i < kmax) {
+      // the 3M product in the form  k1 = (ar + ai) br,  k2 = ar (br + bi),  k3 = ai (br - bi):  re = k1 - k3,  im = k1 - k2 -- two additions per
+      // element behind the block instead of three (and two per fragment, shared by both tiles, instead of one)
+      const double sp = fr[i].x + fr[i].y, sm = fr[i].x - fr[i].y;
+      p1 = __builtin_amdgcn_mfma_f64_16x16x4f64(s0[i], fr[i].x, p1, 0, 0, 0);
+      p2 = __builtin_amdgcn_mfma_f64_16x16x4f64(t0.re[i], sp, p2, 0, 0, 0);
+      p3 = __builtin_amdgcn_mfma_f64_16x16x4f64(t0.im[i], sm, p3, 0, 0, 0);
+      if (HAS1) {
+        r1 = __builtin_amdgcn_mfma_f64_16x16x4f64(s1[i], fr[i].x, r1, 0, 0, 0);
+        r2 = __builtin_amdgcn_mfma_f64_16x16x4f64(t1.re[i], sp, r2, 0, 0, 0);
+        r3 = __builtin_amdgcn_mfma_f64_16x16x4f64(t1.im[i], sm, r3, 0, 0, 0);
+      }
+    }
+    fr[i] = qkf_ldg_a(i == 0 ? b0 : i == 1 ? b1 : i == 2 ? b2 : b3, off);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  QKF_PRIO_HI();
+  {
+    const v4d re = p1 - p3, im = p1 - p2;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      __hip_atomic_fetch_add(d + r * rs, re[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      __hip_atomic_fetch_add(d + r * rs + 1, im[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+  }
+  if (HAS1) {
+    const v4d re = r1 - r3, im = r1 - r2;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      __hip_atomic_fetch_add(d1 + r * rs, re[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      __hip_atomic_fetch_add(d1 + r * rs + 1, im[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+  }
+}
+// the loop of the DET forms (ordered accumulation): one body for every column block, the last one selecting `nxt`, the product in its first 3M
+// form (measured: the split loop of the plain form makes the ordered form 3.5 % slower)
+template <bool FULL, bool HAS1, bool DET>
+__device__ __forceinline__ void qkf_p2_dual_turn(const QkfTile& t0, const QkfTile& t1, v2d (&fr)[4], v2d (&fs)[4], QkfStream cur, const int a2, const int nn, const int kmax, lds_v2d* xo, const int q,
                                             const int j, const QkfStream nxt, const bool nxt_p1, const unsigned n1, const QkfTurn turn = QkfTurn{nullptr, 0, nullptr, nullptr}) {
   __attribute__((address_space(3))) double* d = (__attribute__((address_space(3))) double*)(xo + q * a2 + j);
 #pragma unroll 1
@@ -719,6 +821,28 @@ __device__ __forceinline__ void qkf_p2_dual(const QkfTile& t0, const QkfTile& t1
     }
     d += 2 * TILE;
   }
+}
+
+template <bool FULL, bool HAS1, bool DET = false>
+__device__ __forceinline__ void qkf_p2_dual(const QkfTile& t0, const QkfTile& t1, v2d (&fr)[4], v2d (&fs)[4], QkfStream cur, const int a2, const int nn, const int kmax, lds_v2d* xo, const int q,
+                                            const int j, const QkfStream nxt, const bool nxt_p1, const unsigned n1, const QkfTurn turn = QkfTurn{nullptr, 0, nullptr, nullptr}) {
+  if constexpr (DET) {
+    qkf_p2_dual_turn<FULL, HAS1, DET>(t0, t1, fr, fs, cur, a2, nn, kmax, xo, q, j, nxt, nxt_p1, n1, turn);
+    return;
+  }
+  lds_double* d = (lds_double*)(xo + q * a2 + j);
+  lds_double* d1 = d + (long)2 * TILE * a2;  // the second tile's rows: 16 rows further down
+  const long rs = (long)8 * a2;
+  const v4d s0 = t0.re + t0.im, s1 = HAS1 ? t1.re + t1.im : s0;
+  const v2d *const c0 = cur.base, *const c1 = cur.base + cur.step, *const c2 = cur.base + 2 * cur.step, *const c3 = cur.base + 3 * cur.step;
+  unsigned off = cur.off;
+#pragma unroll 1
+  for (int tn = 0; tn + 1 < nn; ++tn) {
+    off += TILE;
+    qkf_p2_block<FULL, HAS1>(t0, t1, s0, s1, fr, kmax, c0, c1, c2, c3, off, d, d1, rs);
+    d += 2 * TILE, d1 += 2 * TILE;
+  }
+  qkf_p2_block<FULL, HAS1>(t0, t1, s0, s1, fr, kmax, nxt.base, nxt.base + nxt.step, nxt.base + 2 * nxt.step, nxt.base + 3 * nxt.step, nxt.off, d, d1, rs);
 }
 
 template <int NW, int XCAP, int WPS, bool DET = false>  // waves per workgroup (a round holds NW pairs of tiles); elements of the LDS X buffer; waves per SIMD (register budget); ordered accumulation (bit-reproducible)
