@@ -51,6 +51,14 @@
 #define QKF_PRIO_HI() __builtin_amdgcn_s_setprio(2)
 typedef double v2d __attribute__((ext_vector_type(2)));
 typedef __attribute__((address_space(3))) v2d lds_v2d;
+// X (b rows x a columns, LDS or the global buffers) is kept in PANELS of 16 columns: element (row, col) sits at
+//     (col / 16) * (rows * 16) + row * 16 + col % 16
+// so that everything a lane adds to its address inside the loops is a constant: a k-step of phase 1 (4 rows) is 64 elements, the four rows
+// q + 4 r of a tile in phase 2 are 64 elements apart, the second tile of a pair (16 rows down) 256 -- immediate offsets of the LDS and
+// global instructions instead of vector additions, which on gfx950 take time from the matrix pipe (lab/tools/mfma_rate.hip).  A row-major
+// X (stride a) costs four additions per group of k-steps in phase 1 and eight per column block in phase 2.
+static constexpr int QKF_XSTEP = 4 * TILE;        // elements between two k-steps of X (phase 1) and between the rows q + 4 r of a tile (phase 2)
+static constexpr int QKF_XBLOCK = TILE * TILE;    // elements of a block of 16 rows of a panel
 
 // Two shapes are shipped (qkgram.hip picks one per launch from the plan's work profile):
 //   <12 waves, 2 slots, 8192-element X buffer, 3 waves per SIMD>: one workgroup per CU -- large bonds (more sites stay LDS-resident)
@@ -103,19 +111,19 @@ __device__ __forceinline__ void qkf_load4(v2d (&fr)[4], const QkfStream& st) {
 
 // Phase 1, one tile (= one item): T[ta, p, tb] = sum_{l < 4 nks} X[l][16 ta + .] * B[l][p][16 tb + .].
 //   B operand: stream `cur` (step = one k-step = 4 rows of b); its first group is already in `fr` when `primed`;
-//   A operand: X element (xp + xoff + i * xstep), X in LDS or in the global buffer.
+//   A operand: X element (xp + xoff + 64 i) of the panel of columns 16 ta .. (k-step i: rows 4 i + q), X in LDS or in the global buffer.
 // Four k-steps of fragments are in flight: the registers of a k-step are reloaded for k-step + 4 right after its
 // MFMAs (sched_barrier keeps that order); in the LAST group they are reloaded with the first group of stream `nxt`
 // -- the wave's next tile, or its first phase-2 group -- so the stream never drains between tiles or across the
 // barriers.  Loads are unconditional (rows up to the padded bond exist and are zero), MFMAs are issued only for the
 // k-steps below the true bond.
 template <typename XPtr>
-__device__ __forceinline__ void qkf_p1_tile(QkfTile& t, v2d (&fr)[4], const bool primed, QkfStream cur, XPtr xp, unsigned xoff, const int xstep, const int nks, const QkfStream nxt) {
+__device__ __forceinline__ void qkf_p1_tile(QkfTile& t, v2d (&fr)[4], const bool primed, QkfStream cur, XPtr xp, unsigned xoff, const int nks, const QkfStream nxt) {
   v4d p1 = {0, 0, 0, 0}, p2 = {0, 0, 0, 0}, p3 = {0, 0, 0, 0};
   v2d fx[4];
   if (!primed) qkf_load4(fr, cur);
 #pragma unroll
-  for (int i = 0; i < 4; ++i) fx[i] = qkf_ldx(xp + i * xstep, xoff);
+  for (int i = 0; i < 4; ++i) fx[i] = qkf_ldx(xp + i * QKF_XSTEP, xoff);
   const int ng = (nks + 3) >> 2, last = nks - 4 * (ng - 1);  // k-steps of the last group: 1..4
   QKF_PRIO_LO();
   int gq = 0;
@@ -123,7 +131,7 @@ __device__ __forceinline__ void qkf_p1_tile(QkfTile& t, v2d (&fr)[4], const bool
   // them -- on gfx950 every vector instruction takes time from the matrix pipe (lab/tools/mfma_rate.hip)
   if (ng >= 2) {
     gq = 1;
-    cur.off += 4 * cur.step, xoff += 4 * xstep;
+    cur.off += 4 * cur.step, xoff += 4 * QKF_XSTEP;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       if (i == 0) {
@@ -134,17 +142,17 @@ __device__ __forceinline__ void qkf_p1_tile(QkfTile& t, v2d (&fr)[4], const bool
       } else {
         qkf_kstep<false>(p1, p2, p3, fx[i].x, fx[i].y, fr[i].x, fr[i].y);
       }
-      fr[i] = qkf_ldg_b(cur.base + i * cur.step, cur.off), fx[i] = qkf_ldx(xp + i * xstep, xoff);
+      fr[i] = qkf_ldg_b(cur.base + i * cur.step, cur.off), fx[i] = qkf_ldx(xp + i * QKF_XSTEP, xoff);
       __builtin_amdgcn_sched_barrier(0);
     }
   }
 #pragma unroll 1
   for (; gq + 1 < ng; ++gq) {
-    cur.off += 4 * cur.step, xoff += 4 * xstep;
+    cur.off += 4 * cur.step, xoff += 4 * QKF_XSTEP;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       qkf_kstep<false>(p1, p2, p3, fx[i].x, fx[i].y, fr[i].x, fr[i].y);
-      fr[i] = qkf_ldg_b(cur.base + i * cur.step, cur.off), fx[i] = qkf_ldx(xp + i * xstep, xoff);
+      fr[i] = qkf_ldg_b(cur.base + i * cur.step, cur.off), fx[i] = qkf_ldx(xp + i * QKF_XSTEP, xoff);
       __builtin_amdgcn_sched_barrier(0);
     }
   }
@@ -210,10 +218,10 @@ __device__ __forceinline__ void qkf_turn_add(__attribute__((address_space(3))) d
 // block lie below the true bond (every block but the last one of a ragged bond); otherwise kmax of them do.  The last
 // group reloads the registers with the first group of `nxt` (the wave's next item, or its first tile of the next site).
 template <bool FULL, bool DET = false>
-__device__ __forceinline__ void qkf_p2_item(const QkfTile& t, v2d (&fr)[4], const bool primed, QkfStream cur, const int a2, const int nn, const int kmax, lds_v2d* xo, const int q,
+__device__ __forceinline__ void qkf_p2_item(const QkfTile& t, v2d (&fr)[4], const bool primed, QkfStream cur, const int ps, const int nn, const int kmax, lds_v2d* xo, const int q,
                                             const int j, const QkfStream nxt, const QkfTurn turn = QkfTurn{nullptr, 0, nullptr, nullptr}) {
   if (!primed) qkf_load4(fr, cur);
-  __attribute__((address_space(3))) double* d = (__attribute__((address_space(3))) double*)(xo + q * a2 + j);
+  __attribute__((address_space(3))) double* d = (__attribute__((address_space(3))) double*)(xo + q * TILE + j);
 #pragma unroll 1
   for (int tn = 0; tn < nn; ++tn) {
     v4d p1 = {0, 0, 0, 0}, p2 = {0, 0, 0, 0}, p3 = {0, 0, 0, 0};
@@ -230,15 +238,15 @@ __device__ __forceinline__ void qkf_p2_item(const QkfTile& t, v2d (&fr)[4], cons
     }
     QKF_PRIO_HI();
     const v4d re = p1 + p2, im = p3 - p1 + p2;
-    if constexpr (DET) qkf_turn_add(d, (long)8 * a2, re, im, turn, tn);
+    if constexpr (DET) qkf_turn_add(d, (long)2 * QKF_XSTEP, re, im, turn, tn);
     else {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        __hip_atomic_fetch_add(d + (long)r * 8 * a2, re[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        __hip_atomic_fetch_add(d + (long)r * 8 * a2 + 1, im[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __hip_atomic_fetch_add(d + r * 2 * QKF_XSTEP, re[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __hip_atomic_fetch_add(d + r * 2 * QKF_XSTEP + 1, im[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       }
     }
-    d += 2 * TILE;
+    d += 2 * ps;  // the next panel
   }
 }
 
@@ -307,7 +315,7 @@ __device__ __forceinline__ void qkf_edge_prefix(const SweepArgs& g, const int xi
     QkfTile T;
     qkf_edge_tile(T, Ly + (long)q * b + tb * TILE + j, b, Lx + (long)q * a + ta * TILE + j, a, ks4);
 #pragma unroll
-    for (int r = 0; r < 4; ++r) xo[(tb * TILE + q + 4 * r) * a + ta * TILE + j] = (v2d){T.re[r], T.im[r]};
+    for (int r = 0; r < 4; ++r) xo[ta * (b * TILE) + (tb * TILE + q + 4 * r) * TILE + j] = (v2d){T.re[r], T.im[r]};  // (panels of 16 columns)
   }
 }
 
@@ -326,7 +334,7 @@ __device__ __forceinline__ void qkf_edge_suffix(const SweepArgs& g, const int xi
     qkf_edge_tile(T, Ry + (long)q * b + tb * TILE + j, b, Rx + (long)q * a + ta * TILE + j, a, ks4);
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const v2d x = xin[(tb * TILE + q + 4 * r) * a + ta * TILE + j];
+      const v2d x = xin[ta * (b * TILE) + (tb * TILE + q + 4 * r) * TILE + j];
       zr += x.x * T.re[r] - x.y * T.im[r], zi += x.x * T.im[r] + x.y * T.re[r];
     }
   }
@@ -566,7 +574,7 @@ __global__ __launch_bounds__(64 * NW, WPS) void qk_sweep_fused_kernel(const Swee
                 const int u = it >> sc.ps, tbl = (u * sc.inv) >> 20, ta = u - tbl * mt;
                 const bool more = s + 1 < L && it + NW < items;  // another tile follows in this phase; else phase 2 starts with item it0
                 const QkfStream nxt = more ? b_stream(sc, s0, it + NW) : a_stream(sc, it0);
-                qkf_p1_tile(T[S - 1], fr, primed, b_stream(sc, s0, it), xbase, (unsigned)(q * a + ta * TILE + j), 4 * a, sc.nks, nxt);
+                qkf_p1_tile(T[S - 1], fr, primed, b_stream(sc, s0, it), xbase, (unsigned)(ta * (b * TILE) + q * TILE + j), sc.nks, nxt);
                 primed = true;
               }
             }
@@ -597,8 +605,8 @@ __global__ __launch_bounds__(64 * NW, WPS) void qk_sweep_fused_kernel(const Swee
             const QkfStream nxt = more ? a_stream(sc, it + NW) : chain ? b_stream(sn, 0, wave) : a_stream(sc, it);
             const int tix = sc.pd * ta + (it & (sc.pd - 1));  // this contribution's place in the order of its block of rows
             const QkfTurn turn{tcur + tbl * sc.nn, tix, tbroken, g.err};
-            if (kmax == 4) qkf_p2_item<true, DET>(T[S - 1], fr, primed, a_stream(sc, it), a2, sc.nn, 4, XL + ob + tbl * TILE * a2, q, j, nxt, turn);
-            else qkf_p2_item<false, DET>(T[S - 1], fr, primed, a_stream(sc, it), a2, sc.nn, kmax, XL + ob + tbl * TILE * a2, q, j, nxt, turn);
+            if (kmax == 4) qkf_p2_item<true, DET>(T[S - 1], fr, primed, a_stream(sc, it), w * QKF_XBLOCK, sc.nn, 4, XL + ob + tbl * QKF_XBLOCK, q, j, nxt, turn);
+            else qkf_p2_item<false, DET>(T[S - 1], fr, primed, a_stream(sc, it), w * QKF_XBLOCK, sc.nn, kmax, XL + ob + tbl * QKF_XBLOCK, q, j, nxt, turn);
             primed = more || chain;
           }
           QKF_STAMP(4);  // phase 2
@@ -607,7 +615,8 @@ __global__ __launch_bounds__(64 * NW, WPS) void qk_sweep_fused_kernel(const Swee
         tsel ^= 1;
         QKF_STAMP(5);      // wait for the other waves' phase 2
         if (!small && nt > W) {  // several strips: this one goes to the other global buffer
-          for (int e = tid; e < w * TILE * a2; e += NT) Gn[(long long)s0 * TILE * a2 + e] = XL[e];
+          for (int tn = 0; tn < sc.nn; ++tn)  // (panel by panel: the strip's rows of a panel are contiguous in both buffers)
+            for (int e = tid; e < w * QKF_XBLOCK; e += NT) Gn[(long long)tn * (sc.b2 * TILE) + s0 * QKF_XBLOCK + e] = XL[tn * w * QKF_XBLOCK + e];
           __syncthreads();
           QKF_STAMP(1);
         }
@@ -650,7 +659,7 @@ __global__ __launch_bounds__(64 * NW, WPS) void qk_sweep_fused_kernel(const Swee
 // of the single-tile form for the same matrix work.  One pair per wave and round, so there are no slots to rotate.
 // ----------------------------------------------------------------------------------------
 template <bool HAS1, typename XPtr>
-__device__ __forceinline__ void qkf_p1_dual(QkfTile& t0, QkfTile& t1, v2d (&fr)[4], v2d (&fs)[4], const bool primed, QkfStream cur, XPtr xp, unsigned xoff, const int xstep, const int nks,
+__device__ __forceinline__ void qkf_p1_dual(QkfTile& t0, QkfTile& t1, v2d (&fr)[4], v2d (&fs)[4], const bool primed, QkfStream cur, XPtr xp, unsigned xoff, const int nks,
                                             const QkfStream nxt) {
   v4d p1 = {0, 0, 0, 0}, p2 = {0, 0, 0, 0}, p3 = {0, 0, 0, 0}, r1 = {0, 0, 0, 0}, r2 = {0, 0, 0, 0}, r3 = {0, 0, 0, 0};
   v2d fx[4];
@@ -660,14 +669,14 @@ __device__ __forceinline__ void qkf_p1_dual(QkfTile& t0, QkfTile& t1, v2d (&fr)[
     for (int i = 0; i < 4; ++i) fs[i] = qkf_ldg(cur.base + i * cur.step, cur.off + TILE);
   }
 #pragma unroll
-  for (int i = 0; i < 4; ++i) fx[i] = qkf_ldx(xp + i * xstep, xoff);
+  for (int i = 0; i < 4; ++i) fx[i] = qkf_ldx(xp + i * QKF_XSTEP, xoff);
   const int ng = (nks + 3) >> 2, last = nks - 4 * (ng - 1);  // k-steps of the last group: 1..4
   QKF_PRIO_LO();
   int gq = 0;
   // (the first k-step of a chain of more than four k-steps STARTS the accumulators -- literal zero as the C operand --: no register moves to zero them)
   if (ng >= 2) {
     gq = 1;
-    cur.off += 4 * cur.step, xoff += 4 * xstep;
+    cur.off += 4 * cur.step, xoff += 4 * QKF_XSTEP;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       if (i == 0) {
@@ -687,20 +696,20 @@ __device__ __forceinline__ void qkf_p1_dual(QkfTile& t0, QkfTile& t1, v2d (&fr)[
       }
       fr[i] = qkf_ldg_b(cur.base + i * cur.step, cur.off);
       if (HAS1) fs[i] = qkf_ldg_b(cur.base + i * cur.step, cur.off + TILE);
-      fx[i] = qkf_ldx(xp + i * xstep, xoff);
+      fx[i] = qkf_ldx(xp + i * QKF_XSTEP, xoff);
       __builtin_amdgcn_sched_barrier(0);
     }
   }
 #pragma unroll 1
   for (; gq + 1 < ng; ++gq) {
-    cur.off += 4 * cur.step, xoff += 4 * xstep;
+    cur.off += 4 * cur.step, xoff += 4 * QKF_XSTEP;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       qkf_kstep<false>(p1, p2, p3, fx[i].x, fx[i].y, fr[i].x, fr[i].y);
       if (HAS1) qkf_kstep<false>(r1, r2, r3, fx[i].x, fx[i].y, fs[i].x, fs[i].y);
       fr[i] = qkf_ldg_b(cur.base + i * cur.step, cur.off);
       if (HAS1) fs[i] = qkf_ldg_b(cur.base + i * cur.step, cur.off + TILE);
-      fx[i] = qkf_ldx(xp + i * xstep, xoff);
+      fx[i] = qkf_ldx(xp + i * QKF_XSTEP, xoff);
       __builtin_amdgcn_sched_barrier(0);
     }
   }
@@ -775,9 +784,9 @@ __device__ __forceinline__ void qkf_p2_block(const QkfTile& t0, const QkfTile& t
 // the loop of the DET forms (ordered accumulation): one body for every column block, the last one selecting `nxt`, the product in its first 3M
 // form (measured: the split loop of the plain form makes the ordered form 3.5 % slower)
 template <bool FULL, bool HAS1, bool DET>
-__device__ __forceinline__ void qkf_p2_dual_turn(const QkfTile& t0, const QkfTile& t1, v2d (&fr)[4], v2d (&fs)[4], QkfStream cur, const int a2, const int nn, const int kmax, lds_v2d* xo, const int q,
+__device__ __forceinline__ void qkf_p2_dual_turn(const QkfTile& t0, const QkfTile& t1, v2d (&fr)[4], v2d (&fs)[4], QkfStream cur, const int ps, const int nn, const int kmax, lds_v2d* xo, const int q,
                                             const int j, const QkfStream nxt, const bool nxt_p1, const unsigned n1, const QkfTurn turn = QkfTurn{nullptr, 0, nullptr, nullptr}) {
-  __attribute__((address_space(3))) double* d = (__attribute__((address_space(3))) double*)(xo + q * a2 + j);
+  __attribute__((address_space(3))) double* d = (__attribute__((address_space(3))) double*)(xo + q * TILE + j);
 #pragma unroll 1
   for (int tn = 0; tn < nn; ++tn) {
     v4d p1 = {0, 0, 0, 0}, p2 = {0, 0, 0, 0}, p3 = {0, 0, 0, 0}, r1 = {0, 0, 0, 0}, r2 = {0, 0, 0, 0}, r3 = {0, 0, 0, 0};
@@ -798,41 +807,41 @@ __device__ __forceinline__ void qkf_p2_dual_turn(const QkfTile& t0, const QkfTil
     QKF_PRIO_HI();
     {
       const v4d re = p1 + p2, im = p3 - p1 + p2;
-      if constexpr (DET) qkf_turn_add(d, (long)8 * a2, re, im, turn, tn);
+      if constexpr (DET) qkf_turn_add(d, (long)2 * QKF_XSTEP, re, im, turn, tn);
       else {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          __hip_atomic_fetch_add(d + (long)r * 8 * a2, re[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-          __hip_atomic_fetch_add(d + (long)r * 8 * a2 + 1, im[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          __hip_atomic_fetch_add(d + r * 2 * QKF_XSTEP, re[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          __hip_atomic_fetch_add(d + r * 2 * QKF_XSTEP + 1, im[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
       }
     }
     if (HAS1) {
       const v4d re = r1 + r2, im = r3 - r1 + r2;
-      __attribute__((address_space(3))) double* const d1 = d + (long)2 * TILE * a2;  // 16 rows further down
-      if constexpr (DET) qkf_turn_add(d1, (long)8 * a2, re, im, QkfTurn{turn.at + nn, turn.idx, turn.broken, turn.gerr}, tn);  // (the counters of the next block of rows follow)
+      __attribute__((address_space(3))) double* const d1 = d + 2 * QKF_XBLOCK;  // 16 rows further down
+      if constexpr (DET) qkf_turn_add(d1, (long)2 * QKF_XSTEP, re, im, QkfTurn{turn.at + nn, turn.idx, turn.broken, turn.gerr}, tn);  // (the counters of the next block of rows follow)
       else {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          __hip_atomic_fetch_add(d1 + (long)r * 8 * a2, re[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-          __hip_atomic_fetch_add(d1 + (long)r * 8 * a2 + 1, im[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          __hip_atomic_fetch_add(d1 + r * 2 * QKF_XSTEP, re[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          __hip_atomic_fetch_add(d1 + r * 2 * QKF_XSTEP + 1, im[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
       }
     }
-    d += 2 * TILE;
+    d += 2 * ps;  // the next panel
   }
 }
 
 template <bool FULL, bool HAS1, bool DET = false>
-__device__ __forceinline__ void qkf_p2_dual(const QkfTile& t0, const QkfTile& t1, v2d (&fr)[4], v2d (&fs)[4], QkfStream cur, const int a2, const int nn, const int kmax, lds_v2d* xo, const int q,
+__device__ __forceinline__ void qkf_p2_dual(const QkfTile& t0, const QkfTile& t1, v2d (&fr)[4], v2d (&fs)[4], QkfStream cur, const int ps, const int nn, const int kmax, lds_v2d* xo, const int q,
                                             const int j, const QkfStream nxt, const bool nxt_p1, const unsigned n1, const QkfTurn turn = QkfTurn{nullptr, 0, nullptr, nullptr}) {
   if constexpr (DET) {
-    qkf_p2_dual_turn<FULL, HAS1, DET>(t0, t1, fr, fs, cur, a2, nn, kmax, xo, q, j, nxt, nxt_p1, n1, turn);
+    qkf_p2_dual_turn<FULL, HAS1, DET>(t0, t1, fr, fs, cur, ps, nn, kmax, xo, q, j, nxt, nxt_p1, n1, turn);
     return;
   }
-  lds_double* d = (lds_double*)(xo + q * a2 + j);
-  lds_double* d1 = d + (long)2 * TILE * a2;  // the second tile's rows: 16 rows further down
-  const long rs = (long)8 * a2;
+  lds_double* d = (lds_double*)(xo + q * TILE + j);
+  lds_double* d1 = d + 2 * QKF_XBLOCK;  // the second tile's rows: 16 rows further down
+  constexpr long rs = 2 * QKF_XSTEP;
   const v4d s0 = t0.re + t0.im, s1 = HAS1 ? t1.re + t1.im : s0;
   const v2d *const c0 = cur.base, *const c1 = cur.base + cur.step, *const c2 = cur.base + 2 * cur.step, *const c3 = cur.base + 3 * cur.step;
   unsigned off = cur.off;
@@ -840,7 +849,7 @@ __device__ __forceinline__ void qkf_p2_dual(const QkfTile& t0, const QkfTile& t1
   for (int tn = 0; tn + 1 < nn; ++tn) {
     off += TILE;
     qkf_p2_block<FULL, HAS1>(t0, t1, s0, s1, fr, kmax, c0, c1, c2, c3, off, d, d1, rs);
-    d += 2 * TILE, d1 += 2 * TILE;
+    d += 2 * ps, d1 += 2 * ps;  // the next panel
   }
   qkf_p2_block<FULL, HAS1>(t0, t1, s0, s1, fr, kmax, nxt.base, nxt.base + nxt.step, nxt.base + 2 * nxt.step, nxt.base + 3 * nxt.step, nxt.off, d, d1, rs);
 }
@@ -985,13 +994,13 @@ __global__ __launch_bounds__(64 * NW, WPS) void qk_sweep_fused_dual_kernel(const
           const int u = v >> sc.ps, tp = (u * sc.inv) >> 20, ta = u - tp * mt;
           if (mine) {
             const QkfStream bs = b_stream(sc, s0, v, un.half), as = a_stream(sc, v);
-            const unsigned xoff = (unsigned)(q * a + ta * TILE + j);
+            const unsigned xoff = (unsigned)(ta * (b * TILE) + q * TILE + j);
             if (xg) {
-              if (has1) qkf_p1_dual<true>(T0, T1, fr, fs, primed, bs, (const v2d*)Gc, xoff, 4 * a, sc.nks, as);
-              else qkf_p1_dual<false>(T0, T1, fr, fs, primed, bs, (const v2d*)Gc, xoff, 4 * a, sc.nks, as);
+              if (has1) qkf_p1_dual<true>(T0, T1, fr, fs, primed, bs, (const v2d*)Gc, xoff, sc.nks, as);
+              else qkf_p1_dual<false>(T0, T1, fr, fs, primed, bs, (const v2d*)Gc, xoff, sc.nks, as);
             } else {
-              if (has1) qkf_p1_dual<true>(T0, T1, fr, fs, primed, bs, (const lds_v2d*)(XL + xb), xoff, 4 * a, sc.nks, as);
-              else qkf_p1_dual<false>(T0, T1, fr, fs, primed, bs, (const lds_v2d*)(XL + xb), xoff, 4 * a, sc.nks, as);
+              if (has1) qkf_p1_dual<true>(T0, T1, fr, fs, primed, bs, (const lds_v2d*)(XL + xb), xoff, sc.nks, as);
+              else qkf_p1_dual<false>(T0, T1, fr, fs, primed, bs, (const lds_v2d*)(XL + xb), xoff, sc.nks, as);
             }
           }
           QKF_STAMP(2);  // phase 1
@@ -1022,15 +1031,15 @@ __global__ __launch_bounds__(64 * NW, WPS) void qk_sweep_fused_dual_kernel(const
               if (nu.mine) nxt = b_stream(sn, 0, nu.v, nu.half), np1 = true;
             }
             const unsigned nd1 = 0;
-            lds_v2d* const xo = XL + ob + (2 * tp + un.half) * TILE * a2;
+            lds_v2d* const xo = XL + ob + (2 * tp + un.half) * QKF_XBLOCK;
             // the turn counters of this block of rows and this contribution's place in their order
             const QkfTurn tp_turn{tcur + (2 * tp + un.half) * sc.nn, sc.pd * ta + (v & (sc.pd - 1)), tbroken, g.err};
             if (has1) {
-              if (kmax == 4) qkf_p2_dual<true, true, DET>(T0, T1, fr, fs, a_stream(sc, v), a2, sc.nn, 4, xo, q, j, nxt, np1, nd1, tp_turn);
-              else qkf_p2_dual<false, true, DET>(T0, T1, fr, fs, a_stream(sc, v), a2, sc.nn, kmax, xo, q, j, nxt, np1, nd1, tp_turn);
+              if (kmax == 4) qkf_p2_dual<true, true, DET>(T0, T1, fr, fs, a_stream(sc, v), w * QKF_XBLOCK, sc.nn, 4, xo, q, j, nxt, np1, nd1, tp_turn);
+              else qkf_p2_dual<false, true, DET>(T0, T1, fr, fs, a_stream(sc, v), w * QKF_XBLOCK, sc.nn, kmax, xo, q, j, nxt, np1, nd1, tp_turn);
             } else {
-              if (kmax == 4) qkf_p2_dual<true, false, DET>(T0, T1, fr, fs, a_stream(sc, v), a2, sc.nn, 4, xo, q, j, nxt, np1, nd1, tp_turn);
-              else qkf_p2_dual<false, false, DET>(T0, T1, fr, fs, a_stream(sc, v), a2, sc.nn, kmax, xo, q, j, nxt, np1, nd1, tp_turn);
+              if (kmax == 4) qkf_p2_dual<true, false, DET>(T0, T1, fr, fs, a_stream(sc, v), w * QKF_XBLOCK, sc.nn, 4, xo, q, j, nxt, np1, nd1, tp_turn);
+              else qkf_p2_dual<false, false, DET>(T0, T1, fr, fs, a_stream(sc, v), w * QKF_XBLOCK, sc.nn, kmax, xo, q, j, nxt, np1, nd1, tp_turn);
             }
             primed = np1;
           }
@@ -1040,7 +1049,8 @@ __global__ __launch_bounds__(64 * NW, WPS) void qk_sweep_fused_dual_kernel(const
         tsel ^= 1;
         QKF_STAMP(5);  // wait for the other waves' phase 2
         if (!small && nt > W) {
-          for (int e = tid; e < w * TILE * a2; e += NT) Gn[(long long)s0 * TILE * a2 + e] = XL[e];
+          for (int tn = 0; tn < sc.nn; ++tn)  // (panel by panel: the strip's rows of a panel are contiguous in both buffers)
+            for (int e = tid; e < w * QKF_XBLOCK; e += NT) Gn[(long long)tn * (sc.b2 * TILE) + s0 * QKF_XBLOCK + e] = XL[tn * w * QKF_XBLOCK + e];
           __syncthreads();
         }
       }
