@@ -65,10 +65,29 @@ static constexpr int QKF_XBLOCK = TILE * TILE;    // elements of a block of 16 r
 //   <8 waves, 1 slot, 4608-element X buffer, 4 waves per SIMD>: two workgroups per CU -- small / medium bonds (the second workgroup
 //                                              fills the first one's barriers and per-site set-up)
 
+// experiment switches (lab builds only: -DQKF_EXPERIMENT -D...; all default to the shipped code)
+#ifndef QKF_LDS3M
+#define QKF_LDS3M 0
+#endif
+#ifndef QKF_P2_PROBE
+#define QKF_P2_PROBE 0
+#endif
+// ABLATION builds of the dual kernel (timing only, WRONG results; lab/tools/r04_run18.sh): bit 0 = no operand sums inside the matrix loops, bit 1 = no global
+// loads inside them, bit 2 = no s_barrier in the step loop, bit 3 = no LDS reads of X inside the loops of phase 1
+#ifndef QKF_ABL
+#define QKF_ABL 0
+#endif
+#define QKF_STEP_BARRIER()                            \
+  do {                                                \
+    if (QKF_ABL & 4) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); \
+    else qk_lds_barrier();                            \
+  } while (0)
+#define QKF_SUM(a, b) ((QKF_ABL & 1) ? (a) : (a) + (b))
+#define QKF_DIF(a, b) ((QKF_ABL & 1) ? (b) : (a) - (b))
 // one complex k-step, 3M form: (ar + i ai) * (br + i s bi), s = +1 | -1 (CONJB)
 template <bool CONJB>
 __device__ __forceinline__ void qkf_kstep(v4d& p1, v4d& p2, v4d& p3, const double ar, const double ai, const double br, const double bi) {
-  const double sa = ar + ai, sb = CONJB ? br - bi : br + bi;
+  const double sa = QKF_SUM(ar, ai), sb = CONJB ? QKF_DIF(br, bi) : QKF_SUM(br, bi);
   p1 = __builtin_amdgcn_mfma_f64_16x16x4f64(ar, br, p1, 0, 0, 0);
   p2 = __builtin_amdgcn_mfma_f64_16x16x4f64(ai, bi, p2, 0, 0, 0);
   p3 = __builtin_amdgcn_mfma_f64_16x16x4f64(sa, sb, p3, 0, 0, 0);
@@ -681,22 +700,22 @@ __device__ __forceinline__ void qkf_p1_dual(QkfTile& t0, QkfTile& t1, v2d (&fr)[
     for (int i = 0; i < 4; ++i) {
       if (i == 0) {
         const v4d z = {0, 0, 0, 0};
-        const double sa = fx[0].x + fx[0].y;
+        const double sa = QKF_SUM(fx[0].x, fx[0].y);
         p1 = __builtin_amdgcn_mfma_f64_16x16x4f64(fx[0].x, fr[0].x, z, 0, 0, 0);
         p2 = __builtin_amdgcn_mfma_f64_16x16x4f64(fx[0].y, fr[0].y, z, 0, 0, 0);
-        p3 = __builtin_amdgcn_mfma_f64_16x16x4f64(sa, fr[0].x + fr[0].y, z, 0, 0, 0);
+        p3 = __builtin_amdgcn_mfma_f64_16x16x4f64(sa, QKF_SUM(fr[0].x, fr[0].y), z, 0, 0, 0);
         if (HAS1) {
           r1 = __builtin_amdgcn_mfma_f64_16x16x4f64(fx[0].x, fs[0].x, z, 0, 0, 0);
           r2 = __builtin_amdgcn_mfma_f64_16x16x4f64(fx[0].y, fs[0].y, z, 0, 0, 0);
-          r3 = __builtin_amdgcn_mfma_f64_16x16x4f64(sa, fs[0].x + fs[0].y, z, 0, 0, 0);
+          r3 = __builtin_amdgcn_mfma_f64_16x16x4f64(sa, QKF_SUM(fs[0].x, fs[0].y), z, 0, 0, 0);
         }
       } else {
         qkf_kstep<false>(p1, p2, p3, fx[i].x, fx[i].y, fr[i].x, fr[i].y);
         if (HAS1) qkf_kstep<false>(r1, r2, r3, fx[i].x, fx[i].y, fs[i].x, fs[i].y);
       }
-      fr[i] = qkf_ldg_b(cur.base + i * cur.step, cur.off);
-      if (HAS1) fs[i] = qkf_ldg_b(cur.base + i * cur.step, cur.off + TILE);
-      fx[i] = qkf_ldx(xp + i * QKF_XSTEP, xoff);
+      if (!(QKF_ABL & 2)) fr[i] = qkf_ldg_b(cur.base + i * cur.step, cur.off);
+      if (HAS1 && !(QKF_ABL & 2)) fs[i] = qkf_ldg_b(cur.base + i * cur.step, cur.off + TILE);
+      if (!(QKF_ABL & 8)) fx[i] = qkf_ldx(xp + i * QKF_XSTEP, xoff);
       __builtin_amdgcn_sched_barrier(0);
     }
   }
@@ -707,9 +726,9 @@ __device__ __forceinline__ void qkf_p1_dual(QkfTile& t0, QkfTile& t1, v2d (&fr)[
     for (int i = 0; i < 4; ++i) {
       qkf_kstep<false>(p1, p2, p3, fx[i].x, fx[i].y, fr[i].x, fr[i].y);
       if (HAS1) qkf_kstep<false>(r1, r2, r3, fx[i].x, fx[i].y, fs[i].x, fs[i].y);
-      fr[i] = qkf_ldg_b(cur.base + i * cur.step, cur.off);
-      if (HAS1) fs[i] = qkf_ldg_b(cur.base + i * cur.step, cur.off + TILE);
-      fx[i] = qkf_ldx(xp + i * QKF_XSTEP, xoff);
+      if (!(QKF_ABL & 2)) fr[i] = qkf_ldg_b(cur.base + i * cur.step, cur.off);
+      if (HAS1 && !(QKF_ABL & 2)) fs[i] = qkf_ldg_b(cur.base + i * cur.step, cur.off + TILE);
+      if (!(QKF_ABL & 8)) fx[i] = qkf_ldx(xp + i * QKF_XSTEP, xoff);
       __builtin_amdgcn_sched_barrier(0);
     }
   }
@@ -719,7 +738,7 @@ __device__ __forceinline__ void qkf_p1_dual(QkfTile& t0, QkfTile& t1, v2d (&fr)[
       qkf_kstep<false>(p1, p2, p3, fx[i].x, fx[i].y, fr[i].x, fr[i].y);
       if (HAS1) qkf_kstep<false>(r1, r2, r3, fx[i].x, fx[i].y, fs[i].x, fs[i].y);
     }
-    fr[i] = qkf_ldg(nxt.base + i * nxt.step, nxt.off);  // the first group of this pair's phase 2 (one stream: A)
+    if (!(QKF_ABL & 2)) fr[i] = qkf_ldg(nxt.base + i * nxt.step, nxt.off);  // the first group of this pair's phase 2 (one stream: A)
     __builtin_amdgcn_sched_barrier(0);
   }
   QKF_PRIO_HI();
@@ -750,7 +769,11 @@ __device__ __forceinline__ void qkf_p2_block(const QkfTile& t0, const QkfTile& t
     if (FULL || i < kmax) {
       // the 3M product in the form  k1 = (ar + ai) br,  k2 = ar (br + bi),  k3 = ai (br - bi):  re = k1 - k3,  im = k1 - k2 -- two additions per
       // element behind the block instead of three (and two per fragment, shared by both tiles, instead of one)
-      const double sp = fr[i].x + fr[i].y, sm = fr[i].x - fr[i].y;
+#if QKF_LDS3M  // (the LDS takes the product's last two additions: p2 = - k2, p3 = - k3 -- the signs ride on the operand sums as source modifiers)
+      const double sp = -fr[i].x - fr[i].y, sm = fr[i].y - fr[i].x;
+#else
+      const double sp = QKF_SUM(fr[i].x, fr[i].y), sm = QKF_DIF(fr[i].x, fr[i].y);
+#endif
       p1 = __builtin_amdgcn_mfma_f64_16x16x4f64(s0[i], fr[i].x, p1, 0, 0, 0);
       p2 = __builtin_amdgcn_mfma_f64_16x16x4f64(t0.re[i], sp, p2, 0, 0, 0);
       p3 = __builtin_amdgcn_mfma_f64_16x16x4f64(t0.im[i], sm, p3, 0, 0, 0);
@@ -760,10 +783,55 @@ __device__ __forceinline__ void qkf_p2_block(const QkfTile& t0, const QkfTile& t
         r3 = __builtin_amdgcn_mfma_f64_16x16x4f64(t1.im[i], sm, r3, 0, 0, 0);
       }
     }
-    fr[i] = qkf_ldg_a(i == 0 ? b0 : i == 1 ? b1 : i == 2 ? b2 : b3, off);
+    if (!(QKF_ABL & 2)) fr[i] = qkf_ldg_a(i == 0 ? b0 : i == 1 ? b1 : i == 2 ? b2 : b3, off);
     __builtin_amdgcn_sched_barrier(0);
   }
   QKF_PRIO_HI();
+#if QKF_LDS3M
+  // re = k1 - k3 and im = k1 - k2 are not formed in registers: the three accumulators go to X' as they are (k1 to both parts), 16 LDS adds per
+  // tile in place of 8 vector additions + 8 LDS adds -- an LDS instruction costs the matrix pipe 1.8 cycles, a v_add_f64 9.2
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    __hip_atomic_fetch_add(d + r * rs, p1[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    __hip_atomic_fetch_add(d + r * rs + 1, p1[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    __hip_atomic_fetch_add(d + r * rs, p3[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    __hip_atomic_fetch_add(d + r * rs + 1, p2[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  }
+  if (HAS1) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      __hip_atomic_fetch_add(d1 + r * rs, r1[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      __hip_atomic_fetch_add(d1 + r * rs + 1, r1[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      __hip_atomic_fetch_add(d1 + r * rs, r3[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      __hip_atomic_fetch_add(d1 + r * rs + 1, r2[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+  }
+#elif QKF_P2_PROBE  // TIMING PROBES (wrong results): 1 = the adds at conflict-free addresses (a lane's re and im 2 KiB apart, lanes 8 bytes apart), 2 = plain stores instead
+                    // of adds, 3 = no LDS instruction at all, 4 = neither the additions nor the LDS instructions
+  {
+    const v4d re = p1 - p3, im = p1 - p2, re1 = r1 - r3, im1 = r1 - r2;
+    lds_double* const e = d - (threadIdx.x & 63);  // the block's base + q * 16 + j (d is 2 (q * 16 + j) doubles into the block)
+    lds_double* const e1 = e + 2 * QKF_XBLOCK;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      if (QKF_P2_PROBE == 1) {
+        __hip_atomic_fetch_add(e + r * 64, re[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __hip_atomic_fetch_add(e + r * 64 + 256, im[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (HAS1) {
+          __hip_atomic_fetch_add(e1 + r * 64, re1[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          __hip_atomic_fetch_add(e1 + r * 64 + 256, im1[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+      } else if (QKF_P2_PROBE == 2) {
+        *(lds_v2d*)(d + r * rs) = (v2d){re[r], im[r]};
+        if (HAS1) *(lds_v2d*)(d1 + r * rs) = (v2d){re1[r], im1[r]};
+      } else if (QKF_P2_PROBE == 3) {
+        asm volatile("" ::"v"(re[r]), "v"(im[r]), "v"(re1[r]), "v"(im1[r]));
+      } else {
+        asm volatile("" ::"v"(p1[r]), "v"(p2[r]), "v"(p3[r]), "v"(r1[r]), "v"(r2[r]), "v"(r3[r]));
+      }
+    }
+  }
+#else
   {
     const v4d re = p1 - p3, im = p1 - p2;
 #pragma unroll
@@ -780,6 +848,7 @@ __device__ __forceinline__ void qkf_p2_block(const QkfTile& t0, const QkfTile& t
       __hip_atomic_fetch_add(d1 + r * rs + 1, im[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
   }
+#endif
 }
 // the loop of the DET forms (ordered accumulation): one body for every column block, the last one selecting `nxt`, the product in its first 3M
 // form (measured: the split loop of the plain form makes the ordered form 3.5 % slower)
@@ -985,7 +1054,7 @@ __global__ __launch_bounds__(64 * NW, WPS) void qk_sweep_fused_dual_kernel(const
           for (int e = tid; e < g.turn_ints; e += NT) turn0[(tsel ^ 1) * g.turn_ints + e] = 0;
         } else if (!small) {
           for (int e = tid; e < w * TILE * a2; e += NT) XL[e] = (v2d){0.0, 0.0};
-          qk_lds_barrier();
+          QKF_STEP_BARRIER();
         }
         for (int r0 = 0; r0 < units; r0 += NW) {  // (LDS-resident sites: one round, or several when X and X' sit side by side)
           const Unit un = unit_of(sc, w, units, r0);
@@ -1005,10 +1074,10 @@ __global__ __launch_bounds__(64 * NW, WPS) void qk_sweep_fused_dual_kernel(const
           }
           QKF_STAMP(2);  // phase 1
           if (small && r0 == 0 && !(DET && pingpong)) {
-            qk_lds_barrier();  // ping-pong: X' is zero everywhere; in place (one round): every wave has read X, it becomes X'
+            QKF_STEP_BARRIER();  // ping-pong: X' is zero everywhere; in place (one round): every wave has read X, it becomes X'
             if (!pingpong && !DET) {
               for (int e = tid; e < n_out; e += NT) XL[e] = (v2d){0.0, 0.0};
-              qk_lds_barrier();
+              QKF_STEP_BARRIER();
             }
           }
           QKF_STAMP(3);  // wait for the other waves' phase 1 (LDS-resident steps), zero X'
@@ -1045,7 +1114,7 @@ __global__ __launch_bounds__(64 * NW, WPS) void qk_sweep_fused_dual_kernel(const
           }
           QKF_STAMP(4);  // phase 2
         }
-        qk_lds_barrier();  // the strip of X' is complete
+        QKF_STEP_BARRIER();  // the strip of X' is complete
         tsel ^= 1;
         QKF_STAMP(5);  // wait for the other waves' phase 2
         if (!small && nt > W) {
