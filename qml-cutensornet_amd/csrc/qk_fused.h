@@ -73,7 +73,7 @@ static constexpr int QKF_XBLOCK = TILE * TILE;    // elements of a block of 16 r
 #define QKF_P2_PROBE 0
 #endif
 // ABLATION builds of the dual kernel (timing only, WRONG results; lab/tools/r04_run18.sh): bit 0 = no operand sums inside the matrix loops, bit 1 = no global
-// loads inside them, bit 2 = no s_barrier in the step loop, bit 3 = no LDS reads of X inside the loops of phase 1
+// loads inside them, bit 2 = no s_barrier in the step loop, bit 3 = no LDS reads of X inside the loops of phase 1; one-wave sweep (qk_sweep_wave2_kernel): bit 4 = no LDS-DMA, bit 5 = no LDS reads of the fragments, bit 6 = no additions behind a T tile
 #ifndef QKF_ABL
 #define QKF_ABL 0
 #endif
@@ -1288,11 +1288,11 @@ __global__ __launch_bounds__(64, 2) void qk_sweep_wave2_kernel(const SweepArgs g
         const char* const src = base + (((lane >> 3) * 2) * ld + (lane & 7) * 2) * ES;
         const int last = (cnt - 1) >> 1;
 #pragma unroll
-        for (int pc = 0; pc < 2; ++pc) __builtin_amdgcn_global_load_lds(src + (min(pc, last) * 16 * ld) * ES, (lds_ptr_t)(ring + f_slot * GROUP + pc * 64), 16, 0, 0);
+        for (int pc = 0; pc < 2; ++pc) if (!(QKF_ABL & 16)) __builtin_amdgcn_global_load_lds(src + (min(pc, last) * 16 * ld) * ES, (lds_ptr_t)(ring + f_slot * GROUP + pc * 64), 16, 0, 0);
       } else {
         const char* const src = base + ((q * 2) * ld + j) * ES;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) __builtin_amdgcn_global_load_lds(src + (min(i, cnt - 1) * 8 * ld) * ES, (lds_ptr_t)(ring + (f_slot * 4 + i) * 64), 16, 0, 0);
+        for (int i = 0; i < 4; ++i) if (!(QKF_ABL & 16)) __builtin_amdgcn_global_load_lds(src + (min(i, cnt - 1) * 8 * ld) * ES, (lds_ptr_t)(ring + (f_slot * 4 + i) * 64), 16, 0, 0);
       }
       f_slot = (f_slot == NG - 1) ? 0 : f_slot + 1;
       if (++f_i == f_n) {
@@ -1318,6 +1318,8 @@ __global__ __launch_bounds__(64, 2) void qk_sweep_wave2_kernel(const SweepArgs g
           const long long bits = __double_as_longlong(h[i]);
           f[i] = (v2d){(double)__int_as_float((int)bits), (double)__int_as_float((int)(bits >> 32))};
         }
+      } else if (QKF_ABL & 32) {
+        asm volatile("" : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3]) : "v"(at));
       } else {
         asm volatile("ds_read_b128 %0, %1" : "=v"(f[0]) : "v"(at));
         asm volatile("ds_read_b128 %0, %1 offset:1024" : "=v"(f[1]) : "v"(at));
@@ -1376,7 +1378,8 @@ __global__ __launch_bounds__(64, 2) void qk_sweep_wave2_kernel(const SweepArgs g
                   }
                 }
                 QkfTile t;
-                t.re = p1 - p2, t.im = p3 - p1 - p2;
+                if (QKF_ABL & 64) t.re = p1, t.im = p3;
+                else t.re = p1 - p2, t.im = p3 - p1 - p2;
                 // ---- N[tn] += T^T conj(A[ta rows, pp, tn cols])
 #pragma unroll
                 for (int tn = 0; tn < 2; ++tn) {

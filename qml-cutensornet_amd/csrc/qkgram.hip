@@ -20,6 +20,12 @@
 #include "qk_host.h"
 #include "qk_ring.h"
 #include "qk_fused.h"
+#ifndef QKF_QUAD
+#define QKF_QUAD 0  // lab builds only (-DQKF_QUAD=1 -I lab): the quad form of the site-fused sweep (lab/qk_quad.h) stands in for the plain dual form
+#endif
+#if QKF_QUAD
+#include "qk_quad.h"
+#endif
 
 #include <algorithm>
 #include <cmath>
@@ -184,9 +190,18 @@ extern "C" int qk_pack_state(int32_t n_sites, const int32_t* bond_dims, const do
     if (det) QKF_KERNEL_TWO_DET<<<dim3((unsigned)(grid_)), dim3(64 * QKF_TWO_NW), (lds_), c->stream>>>(args_);       \
     else QKF_KERNEL_TWO<<<dim3((unsigned)(grid_)), dim3(64 * QKF_TWO_NW), (lds_), c->stream>>>(args_);               \
   } while (0)
+#if QKF_QUAD  // (lab builds: lab/qk_quad.h, 2 x 2 tiles per wave, 8 waves at two per SIMD)
+#define QKF_QUAD_NW 8
+#define QKF_QUAD_WPS 2
+#define QKF_KERNEL_QUAD qk_sweep_fused_quad_kernel<QKF_QUAD_NW, QKF_XCAP_ONE, QKF_QUAD_WPS>
+#else
+#define QKF_QUAD_NW QKF_DUAL_NW
+#define QKF_KERNEL_QUAD QKF_KERNEL_DUAL
+#endif
 #define QKF_LAUNCH_DUAL(det, grid_, lds_, args_)                                                                     \
   do {                                                                                                               \
     if (det) QKF_KERNEL_DUAL_DET<<<dim3((unsigned)(grid_)), dim3(64 * QKF_DUAL_NW), (lds_), c->stream>>>(args_);     \
+    else if (QKF_QUAD) QKF_KERNEL_QUAD<<<dim3((unsigned)(grid_)), dim3(64 * QKF_QUAD_NW), (lds_), c->stream>>>(args_); \
     else QKF_KERNEL_DUAL<<<dim3((unsigned)(grid_)), dim3(64 * QKF_DUAL_NW), (lds_), c->stream>>>(args_);             \
   } while (0)
 
@@ -415,6 +430,7 @@ static int ctx_init(qk_ctx* c, int device_id, int num_cus) {
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(QKF_KERNEL_ONE), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(QKF_KERNEL_TWO), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 / QKF_TWO_WGS));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(QKF_KERNEL_DUAL), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(QKF_KERNEL_QUAD), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(QKF_KERNEL_ONE_DET), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(QKF_KERNEL_TWO_DET), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 / QKF_TWO_WGS));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(QKF_KERNEL_DUAL_DET), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
