@@ -54,6 +54,11 @@ struct SweepArgs {
   unsigned long long* tail;     // per-launch device clocks (s_memrealtime, 100 MHz): [0] first workgroup start, [1] first workgroup exit, [4] last workgroup exit
   unsigned long long* err;      // one word per sweep (both launches): set by a DET kernel whose ordered accumulation ran out of patience (qk_get_stats fails the call)
   unsigned long long* prof;  // diagnostic build only: cycle sums per section (see QK_VARIANT=9)
+  // GANG START (QK_GANG=1; gang_n = workgroups of this launch per XCD, 0 = off): the workgroups of an XCD begin their next pairs together -- they pull
+  // neighbouring pairs of one plan tile, which share their x and y states, and only workgroups that walk those states at the same pace find each
+  // other's fragments in the XCD's L2.  gang[QK_QSTRIDE * xcc]: [0] arrivals, [1] 'stop waiting' (a workgroup ran out of pairs, or a wait ran out).
+  unsigned long long* gang;
+  int gang_n;
   int debug_flags;           // timing experiments only (QK_DEBUG_FLAGS): bit 0 = skip epilogue stores, bit 1 = skip steady-state fetch/stash, bit 2 = skip MFMAs, bit 3 = skip steady-state barriers (all give WRONG results)
   int prio_mode;             // 0: none; 1: second half of the grid at s_setprio 1; 2: odd blocks at s_setprio 1
 };
@@ -81,6 +86,28 @@ __device__ __forceinline__ long long qk_pull(const SweepArgs& g, const int xcc) 
     if (t < n) return g.qstart[qd] + t;
   }
   return -1;
+}
+
+// Gang start (SweepArgs.gang): called by ONE lane of a workgroup behind every qk_pull.  `round` counts this workgroup's pairs.  Never a hang: a wait is
+// bounded (about a millisecond), and the first wait that runs out -- or the first workgroup without a pair -- switches the waiting off for the whole gang.
+__device__ __forceinline__ void qk_gang_sync(const SweepArgs& g, const int xcc, const bool have_pair, int& round) {
+  if (g.gang_n <= 1) return;
+  unsigned long long* const a = g.gang + QK_QSTRIDE * xcc;
+  if (!have_pair) {
+    __hip_atomic_store(a + 1, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return;
+  }
+  const unsigned long long target = (unsigned long long)g.gang_n * (unsigned long long)(++round);
+  __hip_atomic_fetch_add(a, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  for (int spins = 0;; ++spins) {
+    if (__hip_atomic_load(a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= target) return;
+    if (__hip_atomic_load(a + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return;
+    if (spins > 4000) {
+      __hip_atomic_store(a + 1, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      return;
+    }
+    __builtin_amdgcn_s_sleep(8);
+  }
 }
 
 // Device clocks of a launch for the tail accounting (one lane per workgroup): when the first workgroup started, when the first

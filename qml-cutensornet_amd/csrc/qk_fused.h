@@ -73,7 +73,7 @@ static constexpr int QKF_XBLOCK = TILE * TILE;    // elements of a block of 16 r
 #define QKF_P2_PROBE 0
 #endif
 // ABLATION builds of the dual kernel (timing only, WRONG results; lab/tools/r04_run18.sh): bit 0 = no operand sums inside the matrix loops, bit 1 = no global
-// loads inside them, bit 2 = no s_barrier in the step loop, bit 3 = no LDS reads of X inside the loops of phase 1; one-wave sweep (qk_sweep_wave2_kernel): bit 4 = no LDS-DMA, bit 5 = no LDS reads of the fragments, bit 6 = no additions behind a T tile
+// loads inside them, bit 2 = no s_barrier in the step loop, bit 3 = no LDS reads of X inside the loops of phase 1; one-wave sweep (qk_sweep_wave2_kernel): bit 4 = no LDS-DMA, bit 5 = no LDS reads of the fragments, bit 6 = no additions behind a T tile; one-tile kernel (qk_sweep_fused_kernel): bits 0-3 as in the dual kernel, bit 7 = no additions behind a block of phase 2, bit 8 = no LDS adds there
 #ifndef QKF_ABL
 #define QKF_ABL 0
 #endif
@@ -157,11 +157,12 @@ __device__ __forceinline__ void qkf_p1_tile(QkfTile& t, v2d (&fr)[4], const bool
         const v4d z = {0, 0, 0, 0};
         p1 = __builtin_amdgcn_mfma_f64_16x16x4f64(fx[0].x, fr[0].x, z, 0, 0, 0);
         p2 = __builtin_amdgcn_mfma_f64_16x16x4f64(fx[0].y, fr[0].y, z, 0, 0, 0);
-        p3 = __builtin_amdgcn_mfma_f64_16x16x4f64(fx[0].x + fx[0].y, fr[0].x + fr[0].y, z, 0, 0, 0);
+        p3 = __builtin_amdgcn_mfma_f64_16x16x4f64(QKF_SUM(fx[0].x, fx[0].y), QKF_SUM(fr[0].x, fr[0].y), z, 0, 0, 0);
       } else {
         qkf_kstep<false>(p1, p2, p3, fx[i].x, fx[i].y, fr[i].x, fr[i].y);
       }
-      fr[i] = qkf_ldg_b(cur.base + i * cur.step, cur.off), fx[i] = qkf_ldx(xp + i * QKF_XSTEP, xoff);
+      if (!(QKF_ABL & 2)) fr[i] = qkf_ldg_b(cur.base + i * cur.step, cur.off);
+      if (!(QKF_ABL & 8)) fx[i] = qkf_ldx(xp + i * QKF_XSTEP, xoff);
       __builtin_amdgcn_sched_barrier(0);
     }
   }
@@ -171,14 +172,15 @@ __device__ __forceinline__ void qkf_p1_tile(QkfTile& t, v2d (&fr)[4], const bool
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       qkf_kstep<false>(p1, p2, p3, fx[i].x, fx[i].y, fr[i].x, fr[i].y);
-      fr[i] = qkf_ldg_b(cur.base + i * cur.step, cur.off), fx[i] = qkf_ldx(xp + i * QKF_XSTEP, xoff);
+      if (!(QKF_ABL & 2)) fr[i] = qkf_ldg_b(cur.base + i * cur.step, cur.off);
+      if (!(QKF_ABL & 8)) fx[i] = qkf_ldx(xp + i * QKF_XSTEP, xoff);
       __builtin_amdgcn_sched_barrier(0);
     }
   }
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     if (i < last) qkf_kstep<false>(p1, p2, p3, fx[i].x, fx[i].y, fr[i].x, fr[i].y);
-    fr[i] = qkf_ldg(nxt.base + i * nxt.step, nxt.off);
+    if (!(QKF_ABL & 2)) fr[i] = qkf_ldg(nxt.base + i * nxt.step, nxt.off);
     __builtin_amdgcn_sched_barrier(0);
   }
   QKF_PRIO_HI();
@@ -252,13 +254,16 @@ __device__ __forceinline__ void qkf_p2_item(const QkfTile& t, v2d (&fr)[4], cons
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       if (FULL || i < kmax) qkf_kstep<true>(p1, p2, p3, t.re[i], t.im[i], fr[i].x, fr[i].y);
-      fr[i] = qkf_ldg_a(rb + i * rs, cur.off);
+      if (!(QKF_ABL & 2)) fr[i] = qkf_ldg_a(rb + i * rs, cur.off);
       __builtin_amdgcn_sched_barrier(0);
     }
     QKF_PRIO_HI();
-    const v4d re = p1 + p2, im = p3 - p1 + p2;
+    const v4d re = (QKF_ABL & 128) ? p1 : p1 + p2, im = (QKF_ABL & 128) ? p3 : p3 - p1 + p2;
     if constexpr (DET) qkf_turn_add(d, (long)2 * QKF_XSTEP, re, im, turn, tn);
-    else {
+    else if (QKF_ABL & 256) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) asm volatile("" ::"v"(re[r]), "v"(im[r]));
+    } else {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         __hip_atomic_fetch_add(d + r * 2 * QKF_XSTEP, re[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -508,9 +513,14 @@ __global__ __launch_bounds__(64 * NW, WPS) void qk_sweep_fused_kernel(const Swee
   };
   QKF_PROF_DECL();
   const int xcc = qk_xcc_id();
+  int gang_round = 0;  // (gang start: this workgroup's pairs so far)
   if (tid == 0) qk_tail_start(g);
   for (;;) {
-    if (tid == 0) *slot = qk_pull(g, xcc);  // this XCD's queue first: the workgroups that share an L2 stream the same few states
+    if (tid == 0) {
+      const long long pp_ = qk_pull(g, xcc);
+      qk_gang_sync(g, xcc, pp_ >= 0, gang_round);
+      *slot = pp_;
+    }  // this XCD's queue first: the workgroups that share an L2 stream the same few states
     __syncthreads();
     const long long p = *slot;
     __syncthreads();
@@ -576,7 +586,7 @@ __global__ __launch_bounds__(64 * NW, WPS) void qk_sweep_fused_kernel(const Swee
           for (int e = tid; e < g.turn_ints; e += NT) turn0[(tsel ^ 1) * g.turn_ints + e] = 0;
         } else if (!small) {  // zero this strip's X' rows (the LDS-resident path zeroes after phase 1: X is still being read)
           for (int e = tid; e < w * TILE * a2; e += NT) XL[e] = (v2d){0.0, 0.0};
-          qk_lds_barrier();
+          QKF_STEP_BARRIER();
         }
         QKF_STAMP(6);  // strip zeroing
         for (int r0 = 0; r0 < items; r0 += NW * S) {  // (LDS-resident sites: one round, or several when X and X' sit side by side)
@@ -602,10 +612,10 @@ __global__ __launch_bounds__(64 * NW, WPS) void qk_sweep_fused_kernel(const Swee
           else phase1((const lds_v2d*)(XL + xb));
           QKF_STAMP(2);  // phase 1
           if (small && r0 == 0 && !(DET && pingpong)) {
-            qk_lds_barrier();  // ping-pong: X' is zero everywhere; in place (one round): every wave has read X, it becomes X'
+            QKF_STEP_BARRIER();  // ping-pong: X' is zero everywhere; in place (one round): every wave has read X, it becomes X'
             if (!pingpong && !DET) {
               for (int e = tid; e < n_out; e += NT) XL[e] = (v2d){0.0, 0.0};
-              qk_lds_barrier();
+              QKF_STEP_BARRIER();
             }
           }
           QKF_STAMP(3);  // wait for the other waves' phase 1, zero X'
@@ -630,7 +640,7 @@ __global__ __launch_bounds__(64 * NW, WPS) void qk_sweep_fused_kernel(const Swee
           }
           QKF_STAMP(4);  // phase 2
         }
-        qk_lds_barrier();  // the strip of X' is complete
+        QKF_STEP_BARRIER();  // the strip of X' is complete
         tsel ^= 1;
         QKF_STAMP(5);      // wait for the other waves' phase 2
         if (!small && nt > W) {  // several strips: this one goes to the other global buffer
@@ -991,9 +1001,14 @@ __global__ __launch_bounds__(64 * NW, WPS) void qk_sweep_fused_dual_kernel(const
   };
   QKF_PROF_DECL();
   const int xcc = qk_xcc_id();
+  int gang_round = 0;  // (gang start: this workgroup's pairs so far)
   if (tid == 0) qk_tail_start(g);
   for (;;) {
-    if (tid == 0) *slot = qk_pull(g, xcc);  // this XCD's queue first: the workgroups that share an L2 stream the same few states
+    if (tid == 0) {
+      const long long pp_ = qk_pull(g, xcc);
+      qk_gang_sync(g, xcc, pp_ >= 0, gang_round);
+      *slot = pp_;
+    }  // this XCD's queue first: the workgroups that share an L2 stream the same few states
     __syncthreads();
     const long long p = *slot;
     __syncthreads();

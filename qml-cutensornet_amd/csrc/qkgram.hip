@@ -420,7 +420,7 @@ static int ctx_init(qk_ctx* c, int device_id, int num_cus) {
   HIP_TRY(hipEventCreate(&c->ev1));
   HIP_TRY(hipEventCreate(&c->ev_mid));
   HIP_TRY(hipEventCreate(&c->ev_d));
-  HIP_TRY(hipMalloc(&c->counter, (QK_NQ_MAX * QK_QSTRIDE + 8) * sizeof(unsigned long long)));  // queue heads (8 per launch of a split sweep), tail clocks
+  HIP_TRY(hipMalloc(&c->counter, (QK_NQ_MAX * QK_QSTRIDE + 8 + 2 * 8 * QK_QSTRIDE) * sizeof(unsigned long long)));  // queue heads (8 per launch of a split sweep), tail clocks
   HIP_TRY(hipMalloc(&c->prof, 8 * sizeof(unsigned long long)));
   HIP_TRY(hipMemset(c->prof, 0, 8 * sizeof(unsigned long long)));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(qk_sweep_ring_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
@@ -921,12 +921,13 @@ extern "C" int qk_gram_values(qk_ctx* c, const qk_mps_set* xs, const qk_mps_set*
   a.err = tail + 7;
   a.prof = c->prof;
   a.debug_flags = 0, a.prio_mode = 0;
+  a.gang = c->counter + QK_NQ_MAX * QK_QSTRIDE + 8, a.gang_n = 0;  // (the gang start of the site-fused launches: set where they are launched)
 #ifdef QK_LAB  // timing experiments of the lab kernels (they give wrong results by construction): libqklab.so only
   if (const char* v = std::getenv("QK_DEBUG_FLAGS")) a.debug_flags = std::atoi(v);
   if (const char* v = std::getenv("QK_PRIO")) a.prio_mode = std::atoi(v);
 #endif
   HIP_TRY(hipEventRecord(c->ev_d, c->stream));
-  HIP_TRY(hipMemsetAsync(c->counter, 0, (QK_NQ_MAX * QK_QSTRIDE + 8) * sizeof(unsigned long long), c->stream));
+  HIP_TRY(hipMemsetAsync(c->counter, 0, (QK_NQ_MAX * QK_QSTRIDE + 8 + 2 * 8 * QK_QSTRIDE) * sizeof(unsigned long long), c->stream));
   HIP_TRY(hipMemsetAsync(tail, 0xFF, 4 * sizeof(unsigned long long), c->stream));  // the four minima
   c->last.queues = 1, c->last.tail_frac = c->last.second_tail_frac = 0;
   c->tail_pending = false;
@@ -1016,6 +1017,10 @@ extern "C" int qk_gram_values(qk_ctx* c, const qk_mps_set* xs, const qk_mps_set*
     a.x_plane = (long long)xs->max_pad * ys->max_pad;  // complex elements per global X buffer (two per workgroup)
     HIP_TRY(hipEventRecord(c->ev0, c->stream));        // the conversion above is not part of the sweep
     a.nq = plan->nq, c->last.queues = plan->nq > 1 ? 8 : 1, c->tail_pending = true;
+    // gang start (QK_GANG=1, qk_device.h: qk_gang_sync): the workgroups of an XCD begin their pairs together; workgroups per XCD = grid / 8 (round-robin dispatch)
+    const bool gang_on = plan->nq > 1 && std::getenv("QK_GANG") && std::atoi(std::getenv("QK_GANG")) != 0;
+    auto gang_of = [&](const long long grid_) { return gang_on && grid_ >= 16 && grid_ % 8 == 0 ? (int)(grid_ / 8) : 0; };
+    a.gang_n = gang_of(grid);
     // the dual form (pairs of tiles per wave: half the A and X fragments per matrix instruction) against single tiles, same box:
     // uniform bonds 48 / 64 / 96 / 128 / 256: +2 / +4 / +7 / +12 / +19 %; first run of the headline set's split sweep: 255 against 264 ms
     if (mixed) {
@@ -1029,6 +1034,7 @@ extern "C" int qk_gram_values(qk_ctx* c, const qk_mps_set* xs, const qk_mps_set*
         for (int s_ = 0; s_ <= 8; ++s_) a2.qstart[s_] = plan->qstart[8 + s_] - plan->n_first;
       }
       const unsigned g1 = (unsigned)std::min<long long>(a1.npairs, (long long)(fused_two ? QKF_TWO_WGS : 1) * c->num_cus);
+      a1.gang_n = gang_of(g1), a2.gang_n = 0;
       if (fused_two) QKF_LAUNCH_TWO(det, g1, lds_fused, a1);
       else if (dual) QKF_LAUNCH_DUAL(det, g1, lds_fused, a1);
       else QKF_LAUNCH_ONE(det, g1, lds_fused, a1);
@@ -1051,6 +1057,8 @@ extern "C" int qk_gram_values(qk_ctx* c, const qk_mps_set* xs, const qk_mps_set*
         a1.nq = a2.nq = 8;
         for (int s_ = 0; s_ <= 8; ++s_) a2.qstart[s_] = plan->qstart[8 + s_] - plan->n_first;
       }
+      a1.gang_n = gang_of(std::min<long long>(a1.npairs, c->num_cus));
+      a2.gang = a.gang + 8 * QK_QSTRIDE, a2.gang_n = gang_of(std::min<long long>(a2.npairs, (long long)QKF_TWO_WGS * c->num_cus));
       if (dual) QKF_LAUNCH_DUAL(det, std::min<long long>(a1.npairs, c->num_cus), lds_fused, a1);
       else QKF_LAUNCH_ONE(det, std::min<long long>(a1.npairs, c->num_cus), lds_fused, a1);
       HIP_TRY(hipEventRecord(c->ev_mid, c->stream));

@@ -35,7 +35,7 @@ def main():
 
     ref = None
     for st in settings:
-        for k in ("QK_PLAN_XCD", "QK_PLAN_TILE", "QK_PLAN_TILE_X", "QK_PLAN_TILE_Y", "QK_PLAN_ORIENT_TILE", "QK_DETERMINISTIC", "QK_FUSED_SPLIT", "QK_PLAN_SPLIT", "QK_EDGE", "QK_MERGE", "QK_DEBUG_ALIAS", "QK_PLAN_FIT"):
+        for k in ("QK_PLAN_XCD", "QK_PLAN_TILE", "QK_PLAN_TILE_X", "QK_PLAN_TILE_Y", "QK_PLAN_ORIENT_TILE", "QK_DETERMINISTIC", "QK_FUSED_SPLIT", "QK_PLAN_SPLIT", "QK_EDGE", "QK_MERGE", "QK_DEBUG_ALIAS", "QK_PLAN_FIT", "QK_GANG"):
             os.environ.pop(k, None)
         for kv in st:
             k, v = kv.split("=")
