@@ -736,6 +736,28 @@ def test_split_sweep_two_shapes_one_gram(gpu_ctx, monkeypatch):
     assert np.abs(K - K_ref).max() < TOL and np.abs(K - K1).max() < 1e-13 and np.array_equal(K, K.T)
 
 
+def test_gang_start_changes_no_value(gpu_ctx, monkeypatch):
+    """QK_GANG=1 (the workgroups of an XCD begin their pairs together: qk_device.h, qk_gang_sync) is a matter of timing only: same
+    Gram as the free-running launch (up to the arrival order of the LDS adds) and as the oracle; 120 pairs = 15 workgroups per XCD."""
+    import qml_cutensornet_amd as Q
+    from qml_cutensornet_amd import engine
+    from oracle import restatement as R
+
+    rng = np.random.default_rng(77)
+    n = 14
+    caps = [40, 48, 56, 60, 100, 90, 80, 64, 70, 44, 36, 52, 96, 72, 66]
+    xs = [Q.random_mps(n, [min(2 ** min(k, n - k), c) for k in range(n + 1)], rng) for c in caps]
+    K_ref = np.array([[abs(R.mps_inner(x.tensors, y.tensors)) ** 2 for x in xs] for y in xs])
+    monkeypatch.setenv("QK_GANG", "1")
+    with engine.context(0) as ctx1, ctx1.upload(xs) as dx:
+        K_gang = ctx1.gram(dx)
+        assert "fused" in ctx1.stats()["kernel_name"]
+    monkeypatch.delenv("QK_GANG")
+    with engine.context(0) as ctx2, ctx2.upload(xs) as dx:
+        K = ctx2.gram(dx)
+    assert np.abs(K_gang - K_ref).max() < TOL and np.abs(K_gang - K).max() < 1e-13 and np.array_equal(K_gang, K_gang.T)
+
+
 def test_one_class_sets_pick_their_shape_by_site_size(gpu_ctx):
     """A set with ONE class of pairs whose sites all fit the smaller LDS buffer: bonds capped at 48 (3 x 3 tiles per site) stay on
     the two-workgroup shape, bonds capped at 64 (4 x 4 tiles: what QK_MAX_BOND=64 produces) take the 12-wave dual shape -- the
