@@ -112,14 +112,14 @@ __device__ __forceinline__ void qkq_p1(QkfTile (&T)[2][2], v2d (&fr)[4], v2d (&f
 // fr / fs hold the four k-steps of row block ta / ta + 1; each is reloaded right behind its matrix instructions from (b_i, o0) / (b_i, o1)
 // -- the next column block of the same streams, or (LAST) fr alone from the wave's next phase-1 stream.  The row block that may be ragged
 // is the unit's last one (kmax of its k-steps lie below the true bond).  3M product in the form of qkf_p2_block.
-template <bool A1, bool B1, bool LAST>
+template <bool FULL, bool A1, bool B1, bool LAST>
 __device__ __forceinline__ void qkq_p2_block(const QkfTile (&T)[2][2], const v4d (&S)[2][2], v2d (&fr)[4], v2d (&fs)[4], const int kmax, const v2d* const b0, const v2d* const b1,
                                              const v2d* const b2, const v2d* const b3, const unsigned o0, const unsigned o1, lds_double* const d, lds_double* const d1, const long rs) {
   v4d p1 = {0, 0, 0, 0}, p2 = {0, 0, 0, 0}, p3 = {0, 0, 0, 0}, r1 = {0, 0, 0, 0}, r2 = {0, 0, 0, 0}, r3 = {0, 0, 0, 0};
   QKF_PRIO_LO();
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    if (A1 || i < kmax) {
+    if (A1 || FULL || i < kmax) {
       const double sp = fr[i].x + fr[i].y, sm = fr[i].x - fr[i].y;
       p1 = __builtin_amdgcn_mfma_f64_16x16x4f64(S[0][0][i], fr[i].x, p1, 0, 0, 0);
       p2 = __builtin_amdgcn_mfma_f64_16x16x4f64(T[0][0].re[i], sp, p2, 0, 0, 0);
@@ -136,7 +136,7 @@ __device__ __forceinline__ void qkq_p2_block(const QkfTile (&T)[2][2], const v4d
   if (A1) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      if (i < kmax) {
+      if (FULL || i < kmax) {
         const double sp = fs[i].x + fs[i].y, sm = fs[i].x - fs[i].y;
         p1 = __builtin_amdgcn_mfma_f64_16x16x4f64(S[1][0][i], fs[i].x, p1, 0, 0, 0);
         p2 = __builtin_amdgcn_mfma_f64_16x16x4f64(T[1][0].re[i], sp, p2, 0, 0, 0);
@@ -172,7 +172,7 @@ __device__ __forceinline__ void qkq_p2_block(const QkfTile (&T)[2][2], const v4d
 
 // Phase 2 of a quad: all column blocks of a'.  `cur` = the stream of row block ta (ta + 1: a1off elements further), `nxt` = the wave's next
 // phase-1 stream (or a dummy: its own stream again), `ps` = elements per panel of X' (the strip's rows x 16), xo = the unit's first 16 rows of X'.
-template <bool A1, bool B1>
+template <bool FULL, bool A1, bool B1>
 __device__ __forceinline__ void qkq_p2(const QkfTile (&T)[2][2], v2d (&fr)[4], v2d (&fs)[4], const QkfStream cur, const unsigned a1off, const int ps, const int nn, const int kmax, lds_v2d* xo,
                                        const int q, const int j, const QkfStream nxt) {
   lds_double* d = (lds_double*)(xo + q * TILE + j);
@@ -188,10 +188,10 @@ __device__ __forceinline__ void qkq_p2(const QkfTile (&T)[2][2], v2d (&fr)[4], v
 #pragma unroll 1
   for (int tn = 0; tn + 1 < nn; ++tn) {
     o0 += TILE, o1 += TILE;
-    qkq_p2_block<A1, B1, false>(T, S, fr, fs, kmax, c0, c1, c2, c3, o0, o1, d, d1, rs);
+    qkq_p2_block<FULL, A1, B1, false>(T, S, fr, fs, kmax, c0, c1, c2, c3, o0, o1, d, d1, rs);
     d += 2 * ps, d1 += 2 * ps;  // the next panel
   }
-  qkq_p2_block<A1, B1, true>(T, S, fr, fs, kmax, nxt.base, nxt.base + nxt.step, nxt.base + 2 * nxt.step, nxt.base + 3 * nxt.step, nxt.off, 0u, d, d1, rs);
+  qkq_p2_block<FULL, A1, B1, true>(T, S, fr, fs, kmax, nxt.base, nxt.base + nxt.step, nxt.base + 2 * nxt.step, nxt.base + 3 * nxt.step, nxt.off, 0u, d, d1, rs);
 }
 
 template <int NW, int XCAP, int WPS>  // waves per workgroup (a round holds NW quads); elements of the LDS X buffer; waves per SIMD (register budget)
@@ -402,12 +402,19 @@ __global__ __launch_bounds__(64 * NW, WPS) void qk_sweep_fused_quad_kernel(const
             }
             lds_v2d* const xo = XL + ob + un.tb * QKF_XBLOCK;
             const int ps = w * QKF_XBLOCK;
+            // (FULL: every k-step of the unit's last row block lies below the true bond -- the common case gets matrix blocks without a branch;
+            //  the ragged case is one instantiation per shape with the k-steps tested at run time)
+            auto p2 = [&](auto a1_, auto b1_) __attribute__((always_inline)) {
+              constexpr bool A1_ = decltype(a1_)::value, B1_ = decltype(b1_)::value;
+              if (kmax == 4) qkq_p2<true, A1_, B1_>(T, fr, fs, as, a1off, ps, sc.nn, 4, xo, q, j, nxt);
+              else qkq_p2<false, A1_, B1_>(T, fr, fs, as, a1off, ps, sc.nn, kmax, xo, q, j, nxt);
+            };
             if (un.a1) {
-              if (un.b1) qkq_p2<true, true>(T, fr, fs, as, a1off, ps, sc.nn, kmax, xo, q, j, nxt);
-              else qkq_p2<true, false>(T, fr, fs, as, a1off, ps, sc.nn, kmax, xo, q, j, nxt);
+              if (un.b1) p2(std::true_type{}, std::true_type{});
+              else p2(std::true_type{}, std::false_type{});
             } else {
-              if (un.b1) qkq_p2<false, true>(T, fr, fs, as, a1off, ps, sc.nn, kmax, xo, q, j, nxt);
-              else qkq_p2<false, false>(T, fr, fs, as, a1off, ps, sc.nn, kmax, xo, q, j, nxt);
+              if (un.b1) p2(std::false_type{}, std::true_type{});
+              else p2(std::false_type{}, std::false_type{});
             }
             primed = np1;
           } else {
