@@ -719,3 +719,25 @@ def test_bench_quotes_pmc_figures_only_for_the_sources_they_were_taken_on(monkey
     assert per_kernel is None and "stale" in why
     per_kernel, why = bench.quoted_traffic("no_such_config", names)
     assert per_kernel is None and "no committed summary" in why
+
+
+def test_experiment_switches_are_off_in_the_product(built):
+    """The sweep sources carry experiment switches for lab builds (ablations with WRONG results, the quad form, timing probes:
+    lab/tools/build_variants.py).  Their defaults must be the shipped code, build() must not define any of them, and the product
+    library must not contain the lab kernel."""
+    import os
+    import re
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    csrc = os.path.join(root, "qml-cutensornet_amd", "csrc")
+    fused = open(os.path.join(csrc, "qk_fused.h")).read()
+    gram = open(os.path.join(csrc, "qkgram.hip")).read()
+    for text, name in ((fused, "QKF_ABL"), (fused, "QKF_P2_PROBE"), (fused, "QKF_LDS3M"), (fused, "QKF_NT_A"), (fused, "QKF_NT_B"), (gram, "QKF_QUAD")):
+        m = re.search(r"#ifndef %s\n#define %s (\d+)" % (name, name), text)
+        assert m and m.group(1) == "0", name
+    entry = open(os.path.join(root, "__graft_entry__.py")).read()
+    body = entry[entry.index("def build() -> None"):entry.index("def smoke() -> None")]
+    assert "QKF_" not in body and "-D" not in body.replace("-DQK_LAB", "")  # (the lab library's -DQK_LAB is the only define of build())
+    with open(os.path.join(root, "qml-cutensornet_amd", "libqkgram.so"), "rb") as fh:
+        blob = fh.read()
+    assert b"qk_sweep_fused_dual_kernel" in blob and b"qk_sweep_fused_quad_kernel" not in blob
