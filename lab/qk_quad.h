@@ -11,14 +11,20 @@
 // the loops at 11.7 % of its time, the operand sums at 5.3 %, the tails of phase 2 at 3.6 % -- all three are per-fragment or per-block
 // costs, and a 2 x 2 unit has a third fewer fragments and half the blocks per matrix instruction.  It needs ~200 VGPRs: 8 waves per
 // workgroup, two per SIMD (the dual form as 8 waves ties its 12-wave shape: lab/NOTES_r04.md).
-// STATUS: a lab kernel (built only with -DQKF_QUAD=1, lab/libqkgram_quad.so).  Parity-green (fuzz against the oracle 2.7e-15), and 4 % SLOWER than
-// the shipped dual form on cfg4 (367.8 against 353.7 ms, same box): whole quads gain 13 ms over the same kernel dealing column pairs only, but that
-// kernel is 22 ms behind the 8-wave dual form it ought to equal (lab/NOTES_r04.md).
+// STATUS: a lab kernel (built only with -DQKF_QUAD=1, lab/libqkgram_quad.so).  Parity-green (fuzz against the oracle 2.7e-15), and 2 % SLOWER than
+// the shipped dual form on cfg4 (365.1 against 357.9 ms, same box; the dual form as 8 waves: 361.4): whole quads gain 7 - 13 ms over the same kernel
+// dealing column pairs only, but that kernel is 10 - 22 ms behind the 8-wave dual form it ought to equal (lab/NOTES_r04.md).
 // A round deals whole quads while at least half of the waves get one; the remainder of a strip is cut into column pairs (one row block
 // each: two waves per quad) or single tiles (four waves per quad), so that the last round of a site is as short as its tiles allow.
 // fp64, arrival-order accumulation only (QK_DETERMINISTIC=1 stays on the DET forms of qk_fused.h).
 #pragma once
 // (included by csrc/qkgram.hip behind qk_fused.h, whose streams, tiles, tables and edge products it uses)
+
+// ceil(2^20 / d) for d = 0 .. 16 (0 for d = 0): wave-uniform index, so the look-up is a scalar load
+__device__ __forceinline__ int qkq_qinv(const int d) {
+  static constexpr int T[17] = {0, 1048576, 524288, 349526, 262144, 209716, 174763, 149797, 131072, 116509, 104858, 95326, 87382, 80660, 74899, 69906, 65536};
+  return T[d];
+}
 
 struct QkqUnit {
   bool mine, a1, b1;  // this wave has work; the unit has a second row block / a second column block
@@ -253,7 +259,7 @@ __global__ __launch_bounds__(64 * NW, WPS) void qk_sweep_fused_quad_kernel(const
     pc.n2a = 2 * (pc.nA - pc.kq);
     pc.nB = s.pd * pc.ra * pc.qb_f, pc.nC = s.pd * pc.qa_f * pc.rb, pc.nD = s.pd * pc.ra * pc.rb;
     pc.L = pc.kq + pc.n2a + pc.nB + pc.nC + pc.nD;
-    pc.qinv = pc.qa_f > 0 ? ((1 << 20) + pc.qa_f - 1) / pc.qa_f : 0;  // u / qa_f == (u * qinv) >> 20 (exact for u < 2048, qa_f <= 16)
+    pc.qinv = qkq_qinv(pc.qa_f);  // u / qa_f == (u * qinv) >> 20 (exact for u < 2048, qa_f <= 16); from a table: an integer division here costs ~40 instructions per call
     return pc;
   };
   auto unit_of = [&](const QkfSite& s, const int w, const Pieces& pc, const int r0) __attribute__((always_inline)) {
